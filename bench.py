@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the SingleHDR hot path on MI355X (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[2], the configuration the headline metric
+"HDR images/sec/GPU (512x512) end-to-end" is quoted on): full
+deq -> clip -> lin -> apply_rf -> alpha -> hal -> blend inference, batch 16 of
+512x512 synthetic LDR images per GPU, fp32, random-init weights (Keras
+initialisers, non-trivial BatchNorm statistics).  One "step" = one pass of
+the hot path over one batch, inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per
+GPU); inference shards over the batch axis with no data-path collective
+("weak" scaling: every rank processes its own batch).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_{32x32x2,16x16x4}_f32 dense peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def randomise_bn(model, gen):
+    """BN moving stats mu~N(0,0.1), var~U(0.5,1.5); gamma/beta non-trivial."""
+    with torch.no_grad():
+        for name, t, _ in model.named_weights():
+            if name.endswith(".moving_mean") or name.endswith(".beta"):
+                t.copy_(torch.randn(t.shape, generator=gen) * 0.1)
+            elif name.endswith(".moving_variance") or name.endswith(".gamma"):
+                t.copy_(torch.rand(t.shape, generator=gen) + 0.5)
+            elif name.endswith(".bias"):
+                t.copy_(torch.randn(t.shape, generator=gen) * 0.05)
+
+
+def conv_flops(x, w, stride):
+    n, h, wd, _ = x.shape
+    kh, kw, cin, cout = w.shape
+    ho, wo = -(-h // stride), -(-wd // stride)
+    return 2.0 * n * ho * wo * cin * cout * kh * kw
+
+
+def conv_variant(w, x, x2, algo):
+    """Which kernel shdr_conv2d_fwd_f32 dispatches to (mirrors csrc/conv.hip)."""
+    c1 = x.shape[3]
+    c2 = 0 if x2 is None else x2.shape[3]
+    cout = w.shape[3]
+    mfma_ok = c1 % 4 == 0 and c2 % 4 == 0 and cout % 16 == 0 and (c1 + c2) >= 12
+    if algo == 2 or (algo == 0 and not mfma_ok):
+        return "conv_direct_kernel"
+    bn = 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
+    return "conv_mfma_kernel<128,%d>" % bn
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    pkg = importlib.import_module("singlehdr-tf2_amd")
+    K = pkg._ops
+    torch.manual_seed(1234)
+    gen = torch.Generator().manual_seed(4321)
+    deq = pkg.dequantization_net.model()
+    lin = pkg.linearization_net.model()
+    hal = pkg.hallucination_net.model()
+    for m in (deq, lin, hal):
+        randomise_bn(m, gen)
+    run = pkg.pipeline.Inference(deq, lin, hal, None)
+
+    g = torch.Generator().manual_seed(3 + rank)
+    ldr = (torch.round(torch.rand((args.batch, args.size, args.size, 3), generator=g) * 255.0) / 255.0).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = run(ldr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run(ldr)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all())
+    n_gpus = world
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * n_gpus * args.steps / dt
+
+    result = {
+        "metric": "HDR images/sec (512x512) end-to-end inference, deq+lin+hal",
+        "value": round(value, 3), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: full deq+lin+hal inference, batch=%d x %dx%d per GPU, "
+                               "fp32 (exact-fp32 MFMA), histogram B=4/8/16" % (args.batch, args.size, args.size),
+                   "per_gpu_batch": args.batch, "parallelism": "batch-sharded x%d, no collective" % n_gpus},
+    }
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
+    if rank == 0 and not args.no_roofline:
+        records = []
+        orig = K.conv2d
+
+        def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(x, w, bias, stride=stride, x2=x2, **kw)
+            e1.record()
+            records.append((conv_variant(w, x, x2, kw.get("algo", 0)), conv_flops(x, w, stride), e0, e1))
+            return y
+
+        reps = 3
+        K.conv2d = timed_conv
+        try:
+            for _ in range(reps):
+                run(ldr)
+            torch.cuda.synchronize()
+        finally:
+            K.conv2d = orig
+        agg = {}
+        for var, fl, e0, e1 in records:
+            a = agg.setdefault(var, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = max(agg, key=lambda k: agg[k][1])
+        fl, sec, cnt = agg[dom]
+        achieved = fl / sec / 1e12
+        conv_total_flops = sum(a[0] for a in agg.values()) / reps
+        conv_total_sec = sum(a[1] for a in agg.values()) / reps
+        result["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
+            "all_conv": {"tflops": round(conv_total_flops / conv_total_sec / 1e12, 2),
+                         "ms_per_step": round(conv_total_sec * 1e3, 3),
+                         "gflop_per_step": round(conv_total_flops / 1e9, 1)},
+            "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
+                               "launches_per_step": v[2] // reps} for k, v in sorted(agg.items())},
+        }
+
+    # ---- CPU baseline: the float32 NumPy oracle ("port") on a bounded sample, rank 0, N=1 only ------
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        from oracle import nets  # checker / baseline only -- never on the product path
+        table = np.load(os.path.join(ROOT, "singlehdr-tf2_amd", "data", "invemor_g0_hinv11.npy"))
+        params = {k: {n: t.cpu().numpy() for n, t in m.state_dict().items()}
+                  for k, m in (("deq", deq), ("lin", lin), ("hal", hal))}
+        sample = ldr[:1].cpu().numpy()
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        t0 = time.perf_counter()
+        ref = nets.inference(params, sample, table, with_refinement=False)["A_pred"]
+        cpu_dt = time.perf_counter() - t0
+        err = float(np.abs(out[:1].cpu().numpy() - ref).max() / np.abs(ref).max())
+        result["cpu_baseline"] = {
+            "value": round(1.0 / cpu_dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 image %dx%d deq+lin+hal, float32 NumPy/BLAS oracle (proxy for TF2-CPU, which is not "
+                      "installable here), %.1f s" % (args.size, args.size, cpu_dt),
+            "gpu_vs_oracle_rel_err": float("%.3g" % err),
+        }
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/*
+ * libshdr -- MI355X (gfx950) native kernels for the SingleHDR hot path.
+ *
+ * C ABI drop-in boundary.  The reference
+ * (ShinYwings/SingleHDR-tf2) has no native code and no FFI: every entry point
+ * below replaces a *TensorFlow op call site* of the reference, cited per
+ * function as file:line under /root/reference.
+ *
+ * Conventions
+ *  - all tensors are dense NHWC float32 in device memory, owned by the caller;
+ *    the library allocates nothing and keeps no mutable global state;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *    no implicit device synchronisation;
+ *  - return value: SHDR_OK (0) or a negative SHDR_E_* code; the message of the
+ *    last error on the calling thread is available from shdr_last_error();
+ *    shapes, alignment and strides are validated on the host before launch;
+ *  - filters are HWIO ([KH][KW][Cin][Cout] row-major), as in Keras.
+ */
+#ifndef SHDR_H_
+#define SHDR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHDR_OK          0
+#define SHDR_E_SHAPE    (-1)  /* inconsistent / unsupported dimensions          */
+#define SHDR_E_ALIGN    (-2)  /* pointer or channel count not suitably aligned  */
+#define SHDR_E_ARCH     (-3)  /* no gfx950 device / wrong code object           */
+#define SHDR_E_LAUNCH   (-4)  /* hipLaunchKernel reported an error              */
+#define SHDR_E_NULL     (-5)  /* required pointer is NULL                       */
+
+/* activation codes for the conv epilogue */
+#define SHDR_ACT_NONE   0
+#define SHDR_ACT_RELU   1
+#define SHDR_ACT_LRELU  2   /* leaky relu, slope 0.1 (dequantization_net.py:13) */
+#define SHDR_ACT_TANH   3
+
+/* kernel selection for shdr_conv2d_fwd_f32 */
+#define SHDR_ALGO_AUTO    0
+#define SHDR_ALGO_MFMA    1  /* fp32-MFMA implicit GEMM (needs (C1+C2)%4==0, Cout%16==0) */
+#define SHDR_ALGO_DIRECT  2  /* VALU direct convolution (any shape)                     */
+
+const char* shdr_last_error(void);
+/* library / code-object version string, e.g. "libshdr 0.1 gfx950" */
+const char* shdr_version(void);
+
+/* TF 'SAME' rule: out = ceil(in/stride); total = max((out-1)*stride+k-in,0);
+ * *pad_before = total/2 (extra cell goes to the bottom/right). */
+int shdr_same_pad(int in_size, int k, int stride, int* out_size, int* pad_before);
+
+/*
+ * Convolution forward with fused prologue/epilogue.
+ * Replaces tf.keras.layers.Conv2D / tf.nn.conv2d (+bias_add, activation,
+ * inference BatchNormalization, residual add, channel concat) at
+ *   dequantization_net.py:8-9,21-22,27,35-36,46,62-63
+ *   refinement_net.py:8-9,21-22,27,35-36,47,63-66
+ *   linearization_net.py:12-25,55-64,91-92,28-48,67-83
+ *   hallucination_net.py:47-48,63-65,81,87-89,97,101-105,121-123,140-142
+ *   vgg16.py:33-35
+ *
+ * Input  = channel-concat [x1 (C1 ch), x2_scale * x2 (C2 ch)]   (x2 may be NULL, C2 = 0)
+ * y[n,oh,ow,co] = act2( affine( act1( conv + bias ) ) + residual )
+ *   affine(v) = v*scale[co] + shift[co]      (folded inference BN; scale==NULL -> identity)
+ *   residual  = res[n,oh,ow,co] read with channel stride res_cstride (NULL -> 0)
+ */
+typedef struct shdr_conv2d_desc {
+  int32_t N, H, W;          /* input batch / height / width                     */
+  int32_t C1, C2;           /* channels of x1 and x2                            */
+  int32_t Cout, KH, KW;
+  int32_t stride;           /* same in both directions                          */
+  int32_t pad_t, pad_l;     /* zero padding before (top / left)                 */
+  int32_t Ho, Wo;           /* output height / width                            */
+  float   x2_scale;         /* multiplier applied to x2 (hallucination_net.py:101) */
+  int32_t act1, act2;       /* SHDR_ACT_*                                        */
+  int32_t res_cstride;      /* channels per pixel of the residual tensor         */
+  int32_t y_cstride;        /* channels per pixel of y (>= Cout; 0 -> Cout)      */
+  int32_t algo;             /* SHDR_ALGO_*                                       */
+} shdr_conv2d_desc;
+
+int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
+                        const float* x1, const float* x2, const float* w,
+                        const float* bias, const float* scale, const float* shift,
+                        const float* residual, float* y, void* stream);
+
+/* Spatial-aware soft histogram, parametric bin count
+ * (linearization_net.py:336-350).  x [npix, C] -> y [npix, B*C], channel
+ * order [bin1.c0..c(C-1), bin2...].  Bit-exact w.r.t. the IEEE fp32
+ * evaluation of the reference formula. */
+int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, int C, int B, void* stream);
+
+/* Linearization-Net front end (linearization_net.py:310-322):
+ * y = concat[img(3), sobel(6), hist4(12), hist8(24), hist16(48)] zero-padded
+ * to y_channels (93 <= y_channels, y_channels % 4 == 0 recommended: 96). */
+int shdr_lin_frontend_fwd_f32(const float* img, float* y, int N, int H, int W,
+                              int y_channels, void* stream);
+
+/* AveragePooling2D(2,2) VALID (dequantization_net.py:10); H, W even. */
+int shdr_avgpool2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* MaxPool2D(2,2,SAME) on even dims (hallucination_net.py:49,66; vgg16.py:54). */
+int shdr_maxpool2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* MaxPool2D(3,3,stride 2,SAME) (linearization_net.py:94). */
+int shdr_maxpool3s2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* tf.image.resize(x, 2x, BILINEAR), half-pixel centres
+ * (dequantization_net.py:25, hallucination_net.py:86). */
+int shdr_resize2x_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* tf.reduce_mean(x,[1,2]) (linearization_net.py:118): x [N,HW,C] -> y [N,C]. */
+int shdr_gap_fwd_f32(const float* x, float* y, int N, int HW, int C, void* stream);
+
+/* Dense(11) + EMoR PCA decode (linearization_net.py:185-192, 231-253):
+ * out[b,k] = g0[k] + sum_j hinv[k,j] * (feat[b,:] @ wfc[:,j] + bfc[j]).
+ * table = [K,12] (col 0 = g0, cols 1..11 = hinv). */
+int shdr_invcrf_decode_fwd_f32(const float* feat, const float* wfc, const float* bfc,
+                               const float* table, float* out, int B, int F, int K,
+                               void* stream);
+/* linearization_net.py:368-392 (_increase): rf [B,K] -> monotone CDF [B,K]. */
+int shdr_increase_fwd_f32(const float* rf, float* out, int B, int K, void* stream);
+/* tf_utils.apply_rf (tf_utils.py:54-105): x [B, n_per_batch], rf [B,K]. */
+int shdr_apply_rf_fwd_f32(const float* x, const float* rf, float* y, int B,
+                          int64_t n_per_batch, int K, void* stream);
+
+/* Elementwise glue of the step closures ---------------------------------- */
+/* tf.clip_by_value (test_real_refinement.py:91). */
+int shdr_clip_fwd_f32(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
+/* x*255, RGB->BGR, subtract VGG mean (hallucination_net.py:149-153, vgg16.py:101-109). */
+int shdr_vgg_preprocess_fwd_f32(const float* x, float* y, int64_t npix, void* stream);
+/* channel reversal of 3-channel pixels (tf_utils.py:5-13). */
+int shdr_reverse3_fwd_f32(const float* x, float* y, int64_t npix, void* stream);
+/* alpha = clamp((max_c b - 1 + thr)/thr, 0, 1); a = b + alpha * reverse3(hal)
+ * (test_real_refinement.py:98-105, joint_training.py:141-145,165).
+ * alpha_out (npix floats) may be NULL. */
+int shdr_alpha_blend_fwd_f32(const float* b, const float* hal, float* a, float* alpha_out,
+                             int64_t npix, float thr, void* stream);
+/* concat of up to four 3-channel images into out_channels (>= 3*nsrc, zero
+ * padded) -- the Refinement-Net input tf.concat([A,B,C],-1)
+ * (test_real_refinement.py:108). */
+int shdr_pack3_fwd_f32(const float* s0, const float* s1, const float* s2, const float* s3,
+                       int nsrc, float* y, int out_channels, int64_t npix, void* stream);
+/* log(1+10x)/log(11) (joint_training.py:166,173). */
+int shdr_logc_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SHDR_H_ */

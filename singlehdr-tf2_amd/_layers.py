@@ -1,0 +1,159 @@
+"""Keras-like parameter containers for the drop-in network modules.
+
+Mirrors the parts of tf.keras.Model / layers the reference's callers rely on
+(SURVEY.md section 8b): `net(x, training=bool)`, `net.trainable_variables` (ordered:
+attribute-creation order, kernel before bias, gamma before beta), HWIO kernels,
+Keras default initialisers.  Parameters are torch tensors in device memory;
+all arithmetic goes through `_ops` (the HIP kernels).
+"""
+import math
+
+import numpy as np
+import torch
+
+try:
+    from . import _ops as K
+except ImportError:
+    import _ops as K
+
+BN_EPS = 1e-3        # tf.keras.layers.BatchNormalization default epsilon
+BN_MOMENTUM = 0.99   # ... default momentum
+
+
+def default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+class Layer:
+    """Tracks child layers and variables in attribute-creation order, like Keras."""
+
+    def __init__(self):
+        object.__setattr__(self, "_children", [])   # (name, Layer)
+        object.__setattr__(self, "_vars", [])       # (name, tensor, trainable)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, Layer) and not name.startswith("_"):
+            self._children.append((name, value))
+        object.__setattr__(self, name, value)
+
+    def add_weight(self, name, value, trainable=True):
+        value.requires_grad_(trainable)
+        self._vars.append((name, value, trainable))
+        return value
+
+    # -- Keras-compatible views ------------------------------------------------
+    def named_weights(self, prefix=""):
+        """Ordered (name, tensor, trainable) triples: own variables first, then children."""
+        out = [(prefix + n, t, tr) for n, t, tr in self._vars]
+        for cname, child in self._children:
+            out.extend(child.named_weights(prefix + cname + "."))
+        return out
+
+    @property
+    def trainable_variables(self):
+        return [t for _, t, tr in self.named_weights() if tr]
+
+    @property
+    def non_trainable_variables(self):
+        return [t for _, t, tr in self.named_weights() if not tr]
+
+    @property
+    def weights(self):
+        return [t for _, t, _ in self.named_weights()]
+
+    def state_dict(self):
+        return {n: t.detach() for n, t, _ in self.named_weights()}
+
+    def load_numpy(self, params, strict=True):
+        """Copy a {name: ndarray} dict (oracle naming) into the parameters."""
+        own = dict((n, t) for n, t, _ in self.named_weights())
+        if strict and set(own) != set(params):
+            raise KeyError("parameter names differ: missing %s, unexpected %s"
+                           % (sorted(set(own) - set(params)), sorted(set(params) - set(own))))
+        with torch.no_grad():
+            for n, t in own.items():
+                if n in params:
+                    v = torch.as_tensor(np.asarray(params[n]), dtype=torch.float32)
+                    if tuple(v.shape) != tuple(t.shape):
+                        raise ValueError("%s: shape %s != %s" % (n, tuple(v.shape), tuple(t.shape)))
+                    t.copy_(v)
+        return self
+
+    def to(self, device):
+        for n, t, _ in self.named_weights():
+            t.data = t.data.to(device)
+        return self
+
+    def __call__(self, *args, **kwargs):
+        return self.call(*args, **kwargs)
+
+
+def _glorot_uniform(shape, fan_in, fan_out, device):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, dtype=torch.float32) * 2.0 - 1.0).mul_(lim).to(device)
+
+
+class Conv2D(Layer):
+    """tf.keras.layers.Conv2D(filters, kernel_size, strides, padding='SAME', use_bias)."""
+
+    def __init__(self, in_channels, filters, kernel_size, strides=1, use_bias=True, device=None):
+        super().__init__()
+        device = device or default_device()
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.strides = strides if isinstance(strides, int) else strides[0]
+        self.kernel = self.add_weight("kernel", _glorot_uniform((k, k, in_channels, filters),
+                                                                k * k * in_channels, k * k * filters, device))
+        self.bias = self.add_weight("bias", torch.zeros(filters, device=device)) if use_bias else None
+        self._padded = None  # (version, cin_pad, tensor)
+
+    def kernel_padded(self, cin_pad):
+        """Kernel zero-padded along the input-channel axis (cached per parameter version)."""
+        ver = self.kernel._version
+        if self._padded is None or self._padded[0] != ver or self._padded[1] != cin_pad:
+            k = self.kernel.detach()
+            pad = torch.zeros((k.shape[0], k.shape[1], cin_pad, k.shape[3]), device=k.device, dtype=k.dtype)
+            pad[:, :, :k.shape[2], :] = k
+            self._padded = (ver, cin_pad, pad.contiguous())
+        return self._padded[2]
+
+    def call(self, x, **kw):
+        return K.conv2d(x, self.kernel, self.bias, stride=self.strides, **kw)
+
+
+class BatchNormalization(Layer):
+    """tf.keras.layers.BatchNormalization() with Keras defaults (eps 1e-3, momentum 0.99)."""
+
+    def __init__(self, channels, device=None):
+        super().__init__()
+        device = device or default_device()
+        self.gamma = self.add_weight("gamma", torch.ones(channels, device=device))
+        self.beta = self.add_weight("beta", torch.zeros(channels, device=device))
+        self.moving_mean = self.add_weight("moving_mean", torch.zeros(channels, device=device), trainable=False)
+        self.moving_variance = self.add_weight("moving_variance", torch.ones(channels, device=device), trainable=False)
+        self._folded = None
+
+    def folded(self):
+        """(scale, shift) of the inference transform, cached per parameter version:
+        scale = gamma / sqrt(var + eps), shift = beta - mean * scale."""
+        ver = (self.gamma._version, self.beta._version, self.moving_mean._version, self.moving_variance._version)
+        if self._folded is None or self._folded[0] != ver:
+            with torch.no_grad():
+                scale = self.gamma.detach() * torch.rsqrt(self.moving_variance + BN_EPS)
+                shift = self.beta.detach() - self.moving_mean * scale
+            self._folded = (ver, scale.contiguous(), shift.contiguous())
+        return self._folded[1], self._folded[2]
+
+
+class Dense(Layer):
+    """tf.keras.layers.Dense(units)."""
+
+    def __init__(self, in_features, units, device=None):
+        super().__init__()
+        device = device or default_device()
+        self.kernel = self.add_weight("kernel", _glorot_uniform((in_features, units), in_features, units, device))
+        self.bias = self.add_weight("bias", torch.zeros(units, device=device))
+
+
+def is_training(training):
+    """The reference passes `training="training"` (a truthy string) by default."""
+    return bool(training)

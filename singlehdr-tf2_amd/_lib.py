@@ -1,0 +1,79 @@
+"""ctypes binding of libshdr.so (the C-ABI boundary declared in include/shdr.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol
+cannot be resolved, importing/using the ops raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshdr.so")
+
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `shdr_conv2d_desc` (include/shdr.h)."""
+    _fields_ = [("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("C1", ctypes.c_int32), ("C2", ctypes.c_int32),
+                ("Cout", ctypes.c_int32), ("KH", ctypes.c_int32), ("KW", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("pad_t", ctypes.c_int32), ("pad_l", ctypes.c_int32),
+                ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+                ("x2_scale", ctypes.c_float),
+                ("act1", ctypes.c_int32), ("act2", ctypes.c_int32),
+                ("res_cstride", ctypes.c_int32), ("y_cstride", ctypes.c_int32),
+                ("algo", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/shdr.h
+SIGNATURES = {
+    "shdr_last_error": (ctypes.c_char_p, []),
+    "shdr_version": (ctypes.c_char_p, []),
+    "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_soft_hist_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
+    "shdr_lin_frontend_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_avgpool2_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool2_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_resize2x_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_gap_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "shdr_invcrf_decode_fwd_f32": (c_int, [c_ptr] * 5 + [c_int, c_int, c_int, c_ptr]),
+    "shdr_increase_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    "shdr_apply_rf_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr]),
+    "shdr_clip_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_f32, c_ptr]),
+    "shdr_vgg_preprocess_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_reverse3_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_alpha_blend_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
+    "shdr_pack3_fwd_f32": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_ptr]),
+    "shdr_logc_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libshdr.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libshdr.so not found at %s -- build it with `python singlehdr-tf2_amd/build.py` "
+            "(there is no CPU/PyTorch fallback for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().shdr_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))

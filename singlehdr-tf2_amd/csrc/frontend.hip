@@ -1,0 +1,147 @@
+// Linearization-Net front end on gfx950: spatial-aware soft histogram and the
+// fused [img | sobel | hist4 | hist8 | hist16] feature tensor.
+//
+// Both kernels are HBM-write bound (12 B read, 4*3B resp. 384 B written per
+// pixel): one thread produces one 16-byte quad of output channels so that a
+// wavefront writes 1 KiB contiguously; the 3 input floats of a pixel are
+// shared through L1 by the 24 threads that expand it.
+//
+// Bit-exactness: the bin value is evaluated exactly as
+// the reference does -- centre = fp32(2i-1)/fp32(2B) (IEEE divide),
+// d = |x - centre|, h = d < fp32(1/B) ? 1 - d*B : 0 with the multiply and the
+// subtract rounded separately (__fmul_rn/__fsub_rn forbid FMA contraction).
+#include "shdr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float soft_bin(float x, int i /*1..B*/, float two_b, float nb, float thr) {
+#pragma clang fp contract(off)  // this file is also built with -ffp-contract=off
+  const float centre = __fdiv_rn((float)(2 * i - 1), two_b);
+  const float d = fabsf(__fsub_rn(x, centre));
+  return d < thr ? __fsub_rn(1.0f, __fmul_rn(d, nb)) : 0.0f;
+}
+
+// y [npix, B*C], channel ch = (bin-1)*C + c.  Scalar-element version (any B*C).
+__global__ __launch_bounds__(256) void soft_hist_scalar_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, long npix,
+                                                               int C, int B, float thr) {
+  const int CO = B * C;
+  const long total = npix * CO;
+  const float two_b = (float)(2 * B), nb = (float)B;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / CO;
+    const int ch = (int)(e - p * CO);
+    const int bin = ch / C, c = ch - bin * C;
+    y[e] = soft_bin(x[p * C + c], bin + 1, two_b, nb, thr);
+  }
+}
+
+// Quad version: (B*C) % 4 == 0; one float4 store per thread.
+__global__ __launch_bounds__(256) void soft_hist_quad_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ y, long npix,
+                                                             int C, int B, float thr) {
+  const int Q = (B * C) >> 2;
+  const long total = npix * Q;
+  const float two_b = (float)(2 * B), nb = (float)B;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / Q;
+    const int ch0 = (int)(e - p * Q) * 4;
+    const float* xp = x + p * C;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ch = ch0 + k;
+      const int bin = ch / C, c = ch - bin * C;
+      v[k] = soft_bin(xp[c], bin + 1, two_b, nb, thr);
+    }
+    *reinterpret_cast<float4*>(y + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__device__ __forceinline__ int reflect(int i, int n) {  // REFLECT pad by 1
+  return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+}
+
+// Feature channel `ch` (0..92) of pixel (h, w); rgb = centre pixel.
+__device__ __forceinline__ float frontend_channel(const float* __restrict__ img, long ibase, int h,
+                                                  int w, int H, int W, const float* rgb, int ch) {
+  if (ch < 3) return rgb[ch];
+  if (ch < 9) {  // sobel: channel = 3 + c*2 + {0: dy, 1: dx}   (linearization_net.py:312-314)
+    const int c = (ch - 3) >> 1, dir = (ch - 3) & 1;
+    const int hm = reflect(h - 1, H), hp = reflect(h + 1, H);
+    const int wm = reflect(w - 1, W), wp = reflect(w + 1, W);
+    auto at = [&](int hh, int ww) { return img[(ibase + (long)hh * W + ww) * 3 + c]; };
+    if (dir == 0)  // dy: -(row above) + (row below), weights 1 2 1
+      return (at(hp, wm) - at(hm, wm)) + 2.0f * (at(hp, w) - at(hm, w)) + (at(hp, wp) - at(hm, wp));
+    return (at(hm, wp) - at(hm, wm)) + 2.0f * (at(h, wp) - at(h, wm)) + (at(hp, wp) - at(hp, wm));
+  }
+  int idx, B;
+  if (ch < 21) { idx = ch - 9; B = 4; }
+  else if (ch < 45) { idx = ch - 21; B = 8; }
+  else if (ch < 93) { idx = ch - 45; B = 16; }
+  else return 0.0f;
+  const int bin = idx / 3, c = idx - bin * 3;
+  return soft_bin(rgb[c], bin + 1, (float)(2 * B), (float)B, 1.0f / (float)B);
+}
+
+__global__ __launch_bounds__(256) void lin_frontend_kernel(const float* __restrict__ img,
+                                                           float* __restrict__ y, int N, int H,
+                                                           int W, int YC) {
+  const int Q = (YC + 3) >> 2;
+  const long npix = (long)N * H * W;
+  const long total = npix * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / Q;
+    const int ch0 = (int)(e - p * Q) * 4;
+    const int w = (int)(p % W);
+    const long t = p / W;
+    const int h = (int)(t % H);
+    const long ibase = (t / H) * (long)H * W;
+    const float rgb[3] = {img[p * 3], img[p * 3 + 1], img[p * 3 + 2]};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = frontend_channel(img, ibase, h, w, H, W, rgb, ch0 + k);
+    float* yp = y + p * YC + ch0;
+    if ((YC & 3) == 0) {
+      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ch0 + k < YC) yp[k] = v[k];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, int C, int B,
+                                      void* stream) {
+  SHDR_REQUIRE(x && y, SHDR_E_NULL, "soft_hist: null pointer");
+  SHDR_REQUIRE(npix >= 0 && C > 0 && B > 0 && B <= 4096, SHDR_E_SHAPE, "soft_hist: bad shape");
+  if (npix == 0) return SHDR_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float thr = (float)(1.0 / (double)B);  // Python double 1./max_bin cast to fp32
+  if (((B * C) & 3) == 0 && shdr::aligned16(y)) {
+    const long total = (long)npix * ((B * C) >> 2);
+    hipLaunchKernelGGL(soft_hist_quad_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, x, y,
+                       (long)npix, C, B, thr);
+  } else {
+    const long total = (long)npix * B * C;
+    hipLaunchKernelGGL(soft_hist_scalar_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, x,
+                       y, (long)npix, C, B, thr);
+  }
+  return shdr::check_launch("soft_hist");
+}
+
+extern "C" int shdr_lin_frontend_fwd_f32(const float* img, float* y, int N, int H, int W,
+                                         int y_channels, void* stream) {
+  SHDR_REQUIRE(img && y, SHDR_E_NULL, "lin_frontend: null pointer");
+  SHDR_REQUIRE(N > 0 && H >= 2 && W >= 2, SHDR_E_SHAPE, "lin_frontend: need N>0, H,W>=2 (REFLECT pad)");
+  SHDR_REQUIRE(y_channels >= 93, SHDR_E_SHAPE, "lin_frontend: y_channels must be >= 93");
+  SHDR_REQUIRE((y_channels & 3) != 0 || shdr::aligned16(y), SHDR_E_ALIGN, "lin_frontend: y not 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)N * H * W * ((y_channels + 3) >> 2);
+  hipLaunchKernelGGL(lin_frontend_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, img, y, N,
+                     H, W, y_channels);
+  return shdr::check_launch("lin_frontend");
+}

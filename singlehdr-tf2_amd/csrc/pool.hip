@@ -1,0 +1,175 @@
+// Pooling, bilinear 2x resize and global average pooling (NHWC fp32, gfx950).
+// All HBM-bound: one thread per 16-byte channel quad, grid-stride, coalesced
+// along the channel axis (a wavefront touches 1 KiB contiguous).
+#include "shdr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+
+// decode e -> (n, oh, ow, q) for an output of [N, Ho, Wo, 4*Q]
+#define SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n) \
+  const int q = (int)((e) % (Q));                   \
+  long _t = (e) / (Q);                               \
+  const int ow = (int)(_t % (Wo));                   \
+  _t /= (Wo);                                        \
+  const int oh = (int)(_t % (Ho));                   \
+  const long n = _t / (Ho);
+
+// AveragePooling2D(2,2) VALID (dequantization_net.py:10)
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, Q = C >> 2;
+  const long total = (long)N * Ho * Wo * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n)
+    const float* p = x + (((n * H + 2 * oh) * W + 2 * ow) * (long)C + 4 * q);
+    float4 s = add4(add4(ld4(p), ld4(p + C)), add4(ld4(p + (long)W * C), ld4(p + (long)W * C + C)));
+    st4(y + e * 4, make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f));
+  }
+}
+
+// MaxPool2D(2,2,SAME), even dims -> no padding (hallucination_net.py:49, vgg16.py:54)
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, Q = C >> 2;
+  const long total = (long)N * Ho * Wo * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n)
+    const float* p = x + (((n * H + 2 * oh) * W + 2 * ow) * (long)C + 4 * q);
+    st4(y + e * 4, max4(max4(ld4(p), ld4(p + C)), max4(ld4(p + (long)W * C), ld4(p + (long)W * C + C))));
+  }
+}
+
+// MaxPool2D(3,3,stride 2,SAME): Ho = ceil(H/2); pad_total = max((Ho-1)*2+3-H, 0),
+// pad_before = pad_total/2; padded cells never win (linearization_net.py:94).
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int N, int H, int W, int C, int Ho, int Wo,
+                                                         int pt, int pl) {
+  const int Q = C >> 2;
+  const long total = (long)N * Ho * Wo * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n)
+    const float ninf = -__builtin_huge_valf();
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ih = 2 * oh - pt + i;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int iw = 2 * ow - pl + j;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        m = max4(m, ld4(x + (((n * H + ih) * W + iw) * (long)C + 4 * q)));
+      }
+    }
+    st4(y + e * 4, m);
+  }
+}
+
+// tf.image.resize(2x, BILINEAR), half-pixel centres (dequantization_net.py:25):
+// src = (dst+0.5)/2 - 0.5 -> even dst: taps (m-1, m) lerp .75; odd dst: (m, m+1) lerp .25,
+// indices clamped; value = top + (bot - top)*ly with top = l + (r - l)*lx.
+__global__ __launch_bounds__(256) void resize2x_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int N, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W, Q = C >> 2;
+  const long total = (long)N * Ho * Wo * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n)
+    const int hy = oh >> 1, wx = ow >> 1;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    if (oh & 1) { y0 = hy; y1 = min(hy + 1, H - 1); ly = 0.25f; }
+    else        { y0 = max(hy - 1, 0); y1 = hy; ly = 0.75f; }
+    if (ow & 1) { x0 = wx; x1 = min(wx + 1, W - 1); lx = 0.25f; }
+    else        { x0 = max(wx - 1, 0); x1 = wx; lx = 0.75f; }
+    const float* b = x + (n * H * (long)W) * C + 4 * q;
+    const float4 tl = ld4(b + ((long)y0 * W + x0) * C), tr = ld4(b + ((long)y0 * W + x1) * C);
+    const float4 bl = ld4(b + ((long)y1 * W + x0) * C), br = ld4(b + ((long)y1 * W + x1) * C);
+    auto lerp2 = [&](float a, float bb, float c, float d) {
+      const float top = a + (bb - a) * lx, bot = c + (d - c) * lx;
+      return top + (bot - top) * ly;
+    };
+    st4(y + e * 4, make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
+                               lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w)));
+  }
+}
+
+// tf.reduce_mean(x,[1,2]) (linearization_net.py:118): x [N,HW,C] -> y [N,C].
+// grid (C/64, N); thread = (channel quad 0..15, pixel lane 0..15).
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                  int HW, int C) {
+  __shared__ float4 part[16][16];
+  const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + 4 * q;
+  const long n = blockIdx.y;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < C)
+    for (int p = g; p < HW; p += 16) s = add4(s, ld4(x + (n * HW + p) * (long)C + c0));
+  part[g][q] = s;
+  __syncthreads();
+  if (g == 0 && c0 < C) {
+    float4 t = part[0][q];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t = add4(t, part[i][q]);
+    const float inv = 1.0f / (float)HW;
+    st4(y + n * C + c0, make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv));
+  }
+}
+
+int check_nhwc4(const char* op, const void* x, const void* y, int N, int H, int W, int C) {
+  SHDR_REQUIRE(x && y, SHDR_E_NULL, "%s: null pointer", op);
+  SHDR_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, SHDR_E_SHAPE, "%s: non-positive dimension", op);
+  SHDR_REQUIRE((C & 3) == 0, SHDR_E_ALIGN, "%s: C=%d must be a multiple of 4", op, C);
+  SHDR_REQUIRE(shdr::aligned16(x) && shdr::aligned16(y), SHDR_E_ALIGN, "%s: tensors must be 16-byte aligned", op);
+  return SHDR_OK;
+}
+
+}  // namespace
+
+extern "C" int shdr_avgpool2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (int rc = check_nhwc4("avgpool2", x, y, N, H, W, C)) return rc;
+  SHDR_REQUIRE(H >= 2 && W >= 2, SHDR_E_SHAPE, "avgpool2: H, W must be >= 2");
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C);
+  return shdr::check_launch("avgpool2");
+}
+
+extern "C" int shdr_maxpool2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (int rc = check_nhwc4("maxpool2", x, y, N, H, W, C)) return rc;
+  SHDR_REQUIRE((H & 1) == 0 && (W & 1) == 0, SHDR_E_SHAPE, "maxpool2: H=%d, W=%d must be even", H, W);
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C);
+  return shdr::check_launch("maxpool2");
+}
+
+extern "C" int shdr_maxpool3s2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (int rc = check_nhwc4("maxpool3s2", x, y, N, H, W, C)) return rc;
+  int Ho, Wo, pt, pl;
+  shdr_same_pad(H, 3, 2, &Ho, &pt);
+  shdr_same_pad(W, 3, 2, &Wo, &pl);
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C, Ho, Wo, pt, pl);
+  return shdr::check_launch("maxpool3s2");
+}
+
+extern "C" int shdr_resize2x_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (int rc = check_nhwc4("resize2x", x, y, N, H, W, C)) return rc;
+  const long total = (long)N * H * 2 * W * 2 * (C / 4);
+  hipLaunchKernelGGL(resize2x_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C);
+  return shdr::check_launch("resize2x");
+}
+
+extern "C" int shdr_gap_fwd_f32(const float* x, float* y, int N, int HW, int C, void* stream) {
+  if (int rc = check_nhwc4("gap", x, y, N, HW, 1, C)) return rc;
+  hipLaunchKernelGGL(gap_kernel, dim3((C + 63) / 64, N), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, HW, C);
+  return shdr::check_launch("gap");
+}

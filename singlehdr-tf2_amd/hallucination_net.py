@@ -1,0 +1,125 @@
+"""Hallucination-Net on MI355X -- drop-in for the reference module of the same name.
+
+hallucination_net.py:109-190 of the reference: VGG16-shaped encoder, bilinear-up
+decoder with BatchNorm, 1x1 skip fusers.  Input NHWC float32 RGB in [0,1]
+(H, W multiples of 32), output >= 0 in "BGR" order.  All arithmetic runs in the
+libshdr HIP kernels; inference BatchNorm, bias, relu, the sk/255 scaling and the
+channel concat are fused into the convolution.
+"""
+try:
+    from . import _ops as K
+    from ._layers import Layer, Conv2D, BatchNormalization, is_training
+except ImportError:
+    import _ops as K
+    from _layers import Layer, Conv2D, BatchNormalization, is_training
+
+
+def _no_train(training):
+    if is_training(training):
+        raise NotImplementedError(
+            "training-mode BatchNormalization (batch statistics + backward) is not built yet on the "
+            "HIP path; call with training=False")
+
+
+class down1(Layer):
+    """2 x (conv3x3 + relu) -> (maxpool2, pre-pool skip) (hallucination_net.py:43-56)."""
+
+    def __init__(self, inChannels, outChannels, device=None):
+        super().__init__()
+        self.conv1 = Conv2D(inChannels, outChannels, (3, 3), device=device)
+        self.conv2 = Conv2D(outChannels, outChannels, (3, 3), device=device)
+
+    def call(self, x):
+        x = self.conv1(x, act1=K.ACT_RELU)
+        skip_layer = self.conv2(x, act1=K.ACT_RELU)
+        return K.maxpool2(skip_layer), skip_layer
+
+
+class down2(Layer):
+    """3 x (conv3x3 + relu) -> (maxpool2, pre-pool skip) (hallucination_net.py:58-75)."""
+
+    def __init__(self, inChannels, outChannels, device=None):
+        super().__init__()
+        self.conv1 = Conv2D(inChannels, outChannels, (3, 3), device=device)
+        self.conv2 = Conv2D(outChannels, outChannels, (3, 3), device=device)
+        self.conv3 = Conv2D(outChannels, outChannels, (3, 3), device=device)
+
+    def call(self, x):
+        x = self.conv1(x, act1=K.ACT_RELU)
+        x = self.conv2(x, act1=K.ACT_RELU)
+        skip_layer = self.conv3(x, act1=K.ACT_RELU)
+        return K.maxpool2(skip_layer), skip_layer
+
+
+class up(Layer):
+    """bilinear 2x -> conv3x3 -> relu -> BN -> relu (hallucination_net.py:77-91).
+    The reference constructs `conv2` but never calls it, so it owns no weights."""
+
+    def __init__(self, inChannels, outChannels, device=None):
+        super().__init__()
+        self.conv1 = Conv2D(inChannels, outChannels, (3, 3), device=device)
+        self.norm1 = BatchNormalization(outChannels, device=device)
+
+    def call(self, x, training="training"):
+        _no_train(training)
+        x = K.resize2x(x)
+        scale, shift = self.norm1.folded()
+        return self.conv1(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
+
+
+class skipLayer(Layer):
+    """conv1x1(concat[x, sk/255]) (hallucination_net.py:93-107)."""
+
+    def __init__(self, xChannels, skChannels, outChannels, device=None):
+        super().__init__()
+        self.conv1 = Conv2D(xChannels + skChannels, outChannels, (1, 1), device=device)
+
+    def call(self, x, sk, **kw):
+        return self.conv1(x, x2=sk, x2_scale=1.0 / 255, **kw)
+
+
+class model(Layer):
+    def __init__(self, VGG_MEAN=(103.939, 116.779, 123.68), padding="SAME", device=None):
+        super().__init__()
+        self.VGG_MEAN = list(VGG_MEAN)
+        self.d1 = down1(3, 64, device=device)
+        self.d2 = down1(64, 128, device=device)
+        self.d3 = down2(128, 256, device=device)
+        self.d4 = down2(256, 512, device=device)
+        self.d5 = down2(512, 512, device=device)
+        self.conv1 = Conv2D(512, 512, (3, 3), device=device)
+        self.norm1 = BatchNormalization(512, device=device)
+        self.u5 = up(512, 512, device=device)
+        self.s5 = skipLayer(512, 512, 512, device=device)
+        self.u4 = up(512, 512, device=device)
+        self.s4 = skipLayer(512, 512, 512, device=device)
+        self.u3 = up(512, 256, device=device)
+        self.s3 = skipLayer(256, 256, 256, device=device)
+        self.u2 = up(256, 128, device=device)
+        self.s2 = skipLayer(128, 128, 128, device=device)
+        self.u1 = up(128, 64, device=device)
+        self.s1 = skipLayer(64, 64, 64, device=device)
+        self.conv2 = Conv2D(64, 3, (1, 1), device=device)
+        self.norm2 = BatchNormalization(3, device=device)
+        self.s0 = skipLayer(3, 3, 3, device=device)
+
+    def call(self, input_layer, training="training"):
+        _no_train(training)
+        if list(self.VGG_MEAN) != [103.939, 116.779, 123.68]:
+            raise NotImplementedError("custom VGG_MEAN is not supported by the HIP preprocess kernel")
+        bgr = K.vgg_preprocess(input_layer)          # x*255, RGB->BGR, - mean  (:149-153)
+        x, d1 = self.d1(bgr)
+        x, d2 = self.d2(x)
+        x, d3 = self.d3(x)
+        x, d4 = self.d4(x)
+        enc, d5 = self.d5(x)
+        sc, sh = self.norm1.folded()
+        x = self.conv1(enc, scale=sc, shift=sh, act2=K.ACT_RELU)   # conv -> BN -> relu (:163-165)
+        x = self.s5(self.u5(x, training), d5)
+        x = self.s4(self.u4(x, training), d4)
+        x = self.s3(self.u3(x, training), d3)
+        x = self.s2(self.u2(x, training), d2)
+        x = self.s1(self.u1(x, training), d1)
+        sc, sh = self.norm2.folded()
+        x = self.conv2(x, scale=sc, shift=sh, act2=K.ACT_RELU)     # (:183-185)
+        return self.s0(x, bgr, act1=K.ACT_RELU)                    # relu(s0(x, bgr)) (:188-190)

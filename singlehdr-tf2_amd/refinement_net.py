@@ -1,0 +1,22 @@
+"""Refinement-Net on MI355X -- drop-in for the reference module of the same name.
+
+refinement_net.py:31-66 of the reference: the Dequantization-Net U-Net with a
+9-channel input [A, B, C], bottleneck 128, no tanh; output
+relu(input[..., 0:3] + conv).  `training` is ignored (no BatchNorm).
+"""
+try:
+    from . import _ops as K
+    from .dequantization_net import _unet, down, up  # noqa: F401  (same blocks, refinement_net.py:4-29)
+except ImportError:
+    import _ops as K
+    from dequantization_net import _unet, down, up  # noqa: F401
+
+
+class model(_unet):
+    def __init__(self, strides=(1, 1), padding="SAME", device=None):
+        super().__init__(9, 128, device=device)
+
+    def call(self, input_images, training="training"):
+        x = self._trunk(input_images)
+        # relu(input[..., 0:3] + out(x))  (refinement_net.py:63-66): residual read with channel stride 9
+        return self.out(x, residual=input_images, act2=K.ACT_RELU)

@@ -1,0 +1,54 @@
+"""VGG16 feature extractor (conv1_1 .. pool3) on MI355X -- drop-in for the reference `vgg16`.
+
+vgg16.py:56-133 of the reference: frozen filters from `vgg16.npy`
+(dict name -> [HWIO kernel, bias]); input RGB in [0,1]; returns
+(pool1, pool2, pool3).  The weights are constants (no trainable variables).
+"""
+import inspect
+import os
+
+import numpy as np
+import torch
+
+try:
+    from . import _ops as K
+    from ._layers import Layer, default_device
+except ImportError:
+    import _ops as K
+    from _layers import Layer, default_device
+
+_LAYERS = (("conv1_1", 3, 64), ("conv1_2", 64, 64), ("conv2_1", 64, 128), ("conv2_2", 128, 128),
+           ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256))
+
+
+class Vgg16(Layer):
+    def __init__(self, vgg16_npy_path=None, VGG_MEAN=(103.939, 116.779, 123.68), device=None, data_dict=None):
+        super().__init__()
+        device = device or default_device()
+        if data_dict is None:
+            if vgg16_npy_path is None:  # vgg16.py:60-65: vgg16.npy beside the module
+                path = os.path.abspath(os.path.join(inspect.getfile(Vgg16), os.pardir))
+                vgg16_npy_path = os.path.join(path, "vgg16.npy")
+            data_dict = np.load(vgg16_npy_path, encoding="latin1", allow_pickle=True).item()
+        self.VGG_MEAN = list(VGG_MEAN)
+        self.params = {}
+        for name, cin, cout in _LAYERS:
+            w = torch.as_tensor(np.asarray(data_dict[name][0]), dtype=torch.float32)
+            b = torch.as_tensor(np.asarray(data_dict[name][1]), dtype=torch.float32)
+            if tuple(w.shape) != (3, 3, cin, cout) or tuple(b.shape) != (cout,):
+                raise ValueError("vgg16: %s has shape %s / %s" % (name, tuple(w.shape), tuple(b.shape)))
+            self.params[name] = (w.contiguous().to(device), b.contiguous().to(device))
+
+    def _conv(self, name, x):
+        w, b = self.params[name]
+        return K.conv2d(x, w, b, act1=K.ACT_RELU)   # vgg16.py:33-35
+
+    def call(self, rgb, training="training"):
+        x = K.vgg_preprocess(rgb)                    # vgg16.py:101-109
+        x = self._conv("conv1_2", self._conv("conv1_1", x))
+        pool1 = K.maxpool2(x)
+        x = self._conv("conv2_2", self._conv("conv2_1", pool1))
+        pool2 = K.maxpool2(x)
+        x = self._conv("conv3_3", self._conv("conv3_2", self._conv("conv3_1", pool2)))
+        pool3 = K.maxpool2(x)
+        return pool1, pool2, pool3

@@ -1,0 +1,99 @@
+"""GPU parity tests, per network and end to end, against the float64 oracle and the
+committed golden vectors.  Bar (BASELINE.json north_star): <= 1e-4 relative fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, quantised_image, rel_err
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def build(shdr, name, seed):
+    mod = {"deq": "dequantization_net", "lin": "linearization_net", "hal": "hallucination_net", "ref": "refinement_net"}[name]
+    p = nets.init_params(getattr(nets, name + "_spec")(), seed)
+    return getattr(shdr, mod).model().load_numpy(p), p
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (32, 96)])
+def test_dequantization_net_parity(shdr, hw):
+    m, p = build(shdr, "deq", 21)
+    x = quantised_image(np.random.default_rng(1), (2,) + hw + (3,))
+    y = m(dev(x), training=False)
+    ref = nets.deq_forward(p, x)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+
+
+def test_refinement_net_parity(shdr):
+    m, p = build(shdr, "ref", 22)
+    x = np.random.default_rng(2).random((1, 64, 64, 9))
+    assert rel_err(host(m(dev(x), training=False)), nets.ref_forward(p, x)) <= TOL
+
+
+def test_hallucination_net_parity(shdr):
+    m, p = build(shdr, "hal", 23)
+    x = quantised_image(np.random.default_rng(3), (1, 64, 96, 3))
+    y = host(m(dev(x), training=False))
+    ref = nets.hal_forward(p, x)
+    assert (y >= 0).all() and rel_err(y, ref) <= TOL
+
+
+def test_linearization_net_parity(shdr, emor_table):
+    m, p = build(shdr, "lin", 24)
+    x = quantised_image(np.random.default_rng(4), (2, 64, 64, 3))
+    y = host(m(dev(x), training=False))
+    ref = nets.lin_forward(p, x, emor_table)
+    assert y.shape == (2, 1024) and rel_err(y, ref) <= TOL
+    assert (y[:, 0] == 0).all() and (np.diff(y, axis=1) >= 0).all()
+    # public helpers of the reference class
+    h = host(m.histogram_layer(dev(x), 8))
+    from oracle import ops
+    np.testing.assert_array_equal(h, ops.histogram_layer(x.astype(np.float32), 8))
+
+
+def test_vgg16_parity(shdr):
+    p = nets.init_params(nets.vgg_spec(), 25)
+    dd = {n: [p[n + ".kernel"], p[n + ".bias"]] for n in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3")}
+    v = shdr.vgg16.Vgg16(data_dict=dd)
+    x = quantised_image(np.random.default_rng(5), (1, 32, 32, 3))
+    outs = v(dev(x))
+    refs = nets.vgg_forward(p, x)
+    for o, r in zip(outs, refs):
+        assert tuple(o.shape) == r.shape and rel_err(host(o), r) <= TOL
+    assert v.trainable_variables == []
+
+
+def test_inference_pipeline_matches_golden(shdr):
+    g = np.load(os.path.join(GOLDEN, "inference_64.npz"))
+    ms = {k: build(shdr, k, int(g["seed_" + k]))[0] for k in ("deq", "lin", "hal", "ref")}
+    run = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    out = run(dev(g["ldr"]), return_intermediates=True)
+    for key in ("C_pred", "invcrf", "B_pred", "hal", "A_pred", "hdr"):
+        assert rel_err(host(out[key]), g[key]) <= TOL, key
+    hdr = run(dev(g["ldr"]))
+    np.testing.assert_array_equal(host(hdr), host(out["hdr"]))     # deterministic
+
+
+def test_inference_batch_independence_256(shdr):
+    """size-independent property at a BASELINE-sized input: images in a batch do not interact
+    and the result does not depend on the batch they are computed in (inference BN)."""
+    ms = {k: build(shdr, k, 30 + i)[0] for i, k in enumerate(("deq", "lin", "hal", "ref"))}
+    run = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    x = dev(quantised_image(np.random.default_rng(6), (3, 256, 256, 3)))
+    full = host(run(x))
+    single = host(run(x[1:2].contiguous()))
+    np.testing.assert_array_equal(full[1:2], single)
+    assert np.isfinite(full).all() and (full >= 0).all()

@@ -1,0 +1,238 @@
+"""GPU parity tests, per op: HIP kernel (through the C ABI) vs the float64 oracle on
+the same seeded inputs.  Tolerances: <= 1e-5 tensor-relative per layer for
+fp32-accumulated ops (north-star bar is 1e-4 end to end); the soft histogram
+is bit-exact against the float32 oracle."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, quantised_image, rel_err
+from oracle import ops
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _act(v, act):
+    return {0: lambda t: t, 1: ops.relu, 2: ops.leaky_relu, 3: np.tanh}[act](v)
+
+
+def oracle_conv(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=0, scale=None, shift=None,
+                residual=None, act2=0):
+    xin = x if x2 is None else np.concatenate([x, x2 * x2_scale], axis=-1)
+    v = ops.conv2d(xin.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64), stride)
+    v = _act(v, act1)
+    if scale is not None:
+        v = v * scale + shift
+    if residual is not None:
+        v = v + residual[..., :v.shape[-1]]
+    return _act(v, act2)
+
+
+CONV_CASES = [
+    # name, N, H, W, C1, C2, Cout, k, stride, extras
+    ("mfma128_3x3", 2, 16, 16, 64, 0, 128, 3, 1, dict(bias=True, act1=1)),
+    ("mfma64_3x3_ragged", 1, 20, 13, 32, 0, 64, 3, 1, dict(bias=True, act1=2)),
+    ("mfma32_5x5", 1, 16, 24, 32, 0, 32, 5, 1, dict(bias=True, act1=2)),
+    ("mfma16_7x7_natural", 1, 24, 16, 16, 0, 16, 7, 1, dict(bias=True, act1=2)),
+    ("mfma32_5x5_natural_cin16", 1, 16, 16, 16, 0, 32, 5, 1, dict(bias=True)),
+    ("mfma16_cin12_natural", 1, 16, 16, 12, 0, 16, 7, 1, dict(bias=True, act1=2)),
+    ("mfma_concat_16_16", 1, 16, 16, 16, 16, 16, 3, 1, dict(bias=True, act1=2)),
+    ("mfma_concat_scale_1x1", 2, 8, 8, 64, 64, 64, 1, 1, dict(bias=True, x2_scale=1.0 / 255)),
+    ("mfma_7x7_s2_cin96", 1, 32, 32, 96, 0, 64, 7, 2, dict(bias=True, affine=True, act2=1)),
+    ("mfma_1x1_s2", 1, 16, 16, 64, 0, 128, 1, 2, dict(affine=True)),
+    ("mfma_1x1_res_relu", 1, 16, 16, 64, 0, 256, 1, 1, dict(affine=True, residual=True, act2=1)),
+    ("mfma_relu_bn_relu", 1, 16, 16, 128, 0, 64, 3, 1, dict(bias=True, act1=1, affine=True, act2=1)),
+    ("mfma_small_8x8", 2, 8, 8, 128, 0, 128, 3, 1, dict(bias=True, act1=1)),
+    ("mfma_tiny_4x4", 1, 4, 4, 256, 0, 256, 3, 1, dict(bias=True, act1=1)),
+    ("direct_3to16_7x7", 2, 16, 16, 3, 0, 16, 7, 1, dict(bias=True, act1=2)),
+    ("direct_3to64_3x3", 1, 16, 16, 3, 0, 64, 3, 1, dict(bias=True, act1=1)),
+    ("direct_9to16_7x7", 1, 16, 16, 9, 0, 16, 7, 1, dict(bias=True, act1=2)),
+    ("direct_16to3_tanh_res", 1, 16, 16, 16, 0, 3, 3, 1, dict(bias=True, act1=3, residual=True)),
+    ("direct_16to3_res9_relu", 1, 16, 16, 16, 0, 3, 3, 1, dict(bias=True, residual=True, res_c=9, act2=1)),
+    ("direct_64to3_bn_relu", 1, 16, 16, 64, 0, 3, 1, 1, dict(bias=True, affine=True, act2=1)),
+    ("direct_3p3to3_scale_relu", 1, 16, 16, 3, 3, 3, 1, 1, dict(bias=True, x2_scale=1.0 / 255, act1=1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_parity(shdr, case):
+    name, n, h, w, c1, c2, cout, k, stride, ex = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    x = f32(rng.normal(size=(n, h, w, c1)))
+    x2 = f32(rng.normal(size=(n, h, w, c2)) * (255.0 if "x2_scale" in ex else 1.0)) if c2 else None
+    wt = f32(rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2)))
+    bias = f32(rng.normal(size=cout)) if ex.get("bias") else None
+    scale = f32(rng.uniform(0.5, 1.5, cout)) if ex.get("affine") else None
+    shift = f32(rng.normal(size=cout)) if ex.get("affine") else None
+    ho, wo = -(-h // stride), -(-w // stride)
+    res = f32(rng.normal(size=(n, ho, wo, ex.get("res_c", cout)))) if ex.get("residual") else None
+    kw = dict(stride=stride, x2_scale=ex.get("x2_scale", 1.0), act1=ex.get("act1", 0), act2=ex.get("act2", 0))
+    ref = oracle_conv(x, wt, bias, x2=x2, scale=scale, shift=shift, residual=res, **kw)
+    K = shdr._ops
+    y = K.conv2d(dev(x), dev(wt), None if bias is None else dev(bias), x2=None if x2 is None else dev(x2),
+                 scale=None if scale is None else dev(scale), shift=None if shift is None else dev(shift),
+                 residual=None if res is None else dev(res), **kw)
+    assert tuple(y.shape) == ref.shape
+    assert rel_err(host(y), ref) <= TOL
+
+
+def test_conv2d_mfma_and_direct_agree(shdr):
+    """the two kernels are interchangeable where both apply"""
+    rng = np.random.default_rng(7)
+    x, wt, b = f32(rng.normal(size=(1, 12, 12, 16))), f32(rng.normal(size=(3, 3, 16, 16)) / 12), f32(rng.normal(size=16))
+    K = shdr._ops
+    ym = K.conv2d(dev(x), dev(wt), dev(b), algo=K.ALGO_MFMA)
+    yd = K.conv2d(dev(x), dev(wt), dev(b), algo=K.ALGO_DIRECT)
+    assert rel_err(host(ym), host(yd)) <= 2e-6
+    with pytest.raises(RuntimeError, match="MFMA path needs"):
+        K.conv2d(dev(f32(rng.normal(size=(1, 8, 8, 3)))), dev(f32(rng.normal(size=(3, 3, 3, 16)))), algo=K.ALGO_MFMA)
+
+
+def test_conv2d_mfma_layout_exact_integers(shdr):
+    """A = identity-like / asymmetric integer data: catches transposed fragment maps exactly."""
+    rng = np.random.default_rng(8)
+    x = f32(rng.integers(-3, 4, size=(1, 16, 16, 32)))
+    wt = f32(rng.integers(-2, 3, size=(3, 3, 32, 64)))
+    ref = ops.conv2d(x.astype(np.float64), wt.astype(np.float64))
+    y = shdr._ops.conv2d(dev(x), dev(wt))
+    np.testing.assert_array_equal(host(y), ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("B", [4, 5, 7, 8, 16, 32])
+def test_soft_hist_bit_exact(shdr, B):
+    rng = np.random.default_rng(B)
+    x = f32(quantised_image(rng, (2, 17, 9, 3)))
+    x[0, 0, 0] = [0.0, 1.0, 0.5]
+    # values exactly on bin centres / edges
+    x[0, 1, :8, 0] = f32(np.arange(8) / 8.0)
+    ref = ops.histogram_layer(x, B)                  # float32 evaluation of the reference formula
+    y = host(shdr._ops.soft_hist(dev(x), B))
+    assert y.dtype == np.float32 and y.shape == ref.shape
+    np.testing.assert_array_equal(y.view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_array_equal(y > 0, ref > 0)    # "which bins fire" index predicate
+
+
+def test_soft_hist_known_answer_lin2(shdr):
+    x = f32(np.array([0.63, 0.65, 0.32, 0.84, 0.15]).reshape(1, 1, 5, 1))
+    y = host(shdr._ops.soft_hist(dev(x), 5))[0, 0]
+    expect = np.array([[0, 0, .35, .65, 0], [0, 0, .25, .75, 0], [0, .9, .1, 0, 0], [0, 0, 0, .3, .7], [.75, .25, 0, 0, 0]])
+    np.testing.assert_allclose(y, expect, atol=1e-6)
+
+
+def test_soft_hist_and_frontend_golden(shdr):
+    g = np.load(os.path.join(GOLDEN, "frontend_16.npz"))
+    x = dev(g["x"])
+    for b in (4, 5, 8, 16, 32):
+        np.testing.assert_array_equal(host(shdr._ops.soft_hist(x, b)), g["hist%d" % b])
+    fe = host(shdr._ops.lin_frontend(x, 96))
+    np.testing.assert_array_equal(fe[..., :3], g["x"])
+    np.testing.assert_array_equal(fe[..., 9:93], g["frontend93"][..., 9:93])      # histogram channels: bit exact
+    np.testing.assert_allclose(fe[..., 3:9], g["frontend93"][..., 3:9], atol=2e-6)  # sobel: fp32 sum order
+    assert float(np.abs(fe[..., 93:]).max()) == 0.0
+    fe93 = host(shdr._ops.lin_frontend(x, 93))
+    np.testing.assert_array_equal(fe93, fe[..., :93])
+
+
+def test_lin_frontend_parity_ragged(shdr):
+    x = f32(quantised_image(np.random.default_rng(3), (2, 7, 5, 3)))
+    ref = ops.lin_frontend(x.astype(np.float64))
+    y = host(shdr._ops.lin_frontend(dev(x), 96))
+    assert rel_err(y[..., :93], ref) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 6, 6, 64)])
+def test_pools_and_resize_parity(shdr, shape):
+    K = shdr._ops
+    x = f32(np.random.default_rng(5).normal(size=shape))
+    xd = dev(x)
+    np.testing.assert_allclose(host(K.avgpool2(xd)), ops.avg_pool2(x.astype(np.float64)), atol=1e-6)
+    np.testing.assert_array_equal(host(K.maxpool2(xd)), ops.max_pool(x, 2, 2))
+    np.testing.assert_array_equal(host(K.maxpool3s2(xd)), ops.max_pool(x, 3, 2))
+    np.testing.assert_allclose(host(K.resize2x(xd)), ops.resize_bilinear_2x(x.astype(np.float64)), atol=1e-6)
+
+
+def test_maxpool3s2_odd_size(shdr):
+    x = f32(np.random.default_rng(6).normal(size=(1, 7, 9, 8)))
+    np.testing.assert_array_equal(host(shdr._ops.maxpool3s2(dev(x))), ops.max_pool(x, 3, 2))
+
+
+def test_global_avg_pool_parity(shdr):
+    x = f32(np.random.default_rng(7).normal(size=(3, 16, 16, 512)))
+    assert rel_err(host(shdr._ops.global_avg_pool(dev(x))), ops.global_avg_pool(x.astype(np.float64))) <= 1e-6
+    x = f32(np.random.default_rng(8).normal(size=(2, 5, 3, 24)))
+    assert rel_err(host(shdr._ops.global_avg_pool(dev(x))), ops.global_avg_pool(x.astype(np.float64))) <= 1e-6
+
+
+def test_invcrf_head_parity(shdr, emor_table):
+    K = shdr._ops
+    rng = np.random.default_rng(9)
+    feat, wfc, bfc = f32(rng.normal(size=(4, 512))), f32(rng.normal(size=(512, 11)) * 0.05), f32(rng.normal(size=11))
+    w = ops.dense(feat.astype(np.float64), wfc, bfc)
+    ref = ops.invcrf_pca_decode(w, emor_table[:, 0], emor_table[:, 1:])
+    y = K.invcrf_decode(dev(feat), dev(wfc), dev(bfc), dev(emor_table))
+    assert rel_err(host(y), ref) <= 2e-6
+    inc = host(K.increase(y))
+    ref_inc = ops.increase(host(y).astype(np.float64))
+    assert rel_err(inc, ref_inc) <= 2e-6
+    assert (inc[:, 0] == 0).all() and np.allclose(inc[:, -1], 1.0, atol=2e-6) and (np.diff(inc, axis=1) >= 0).all()
+
+
+def test_increase_edge_cases(shdr):
+    K = shdr._ops
+    rf = f32(np.tile(np.linspace(0, 1, 1024)[None], (2, 1)))          # already monotone -> unchanged
+    np.testing.assert_allclose(host(K.increase(dev(rf))), rf, atol=2e-6)
+    rf2 = f32(np.random.default_rng(1).normal(size=(1, 37)))            # ragged K
+    assert rel_err(host(K.increase(dev(rf2))), ops.increase(rf2.astype(np.float64))) <= 2e-6
+
+
+def test_apply_rf_parity(shdr):
+    K = shdr._ops
+    rng = np.random.default_rng(10)
+    x = f32(quantised_image(rng, (3, 8, 8, 3)))
+    x[0, 0, 0] = [0.0, 1.0, 0.5]
+    rf = f32(np.sort(rng.random((3, 1024)), axis=1))
+    assert rel_err(host(K.apply_rf(dev(x), dev(rf))), ops.apply_rf(x.astype(np.float64), rf.astype(np.float64))) <= 1e-6
+    ident = f32(np.tile(np.linspace(0, 1, 1024)[None], (3, 1)))
+    np.testing.assert_allclose(host(K.apply_rf(dev(x), dev(ident))), x, atol=1e-6)
+    xo = f32(rng.random((2, 5, 3)))                                      # n_per_batch not a multiple of 4
+    assert rel_err(host(K.apply_rf(dev(xo), dev(rf[:2]))), ops.apply_rf(xo.astype(np.float64), rf[:2].astype(np.float64))) <= 1e-6
+
+
+def test_glue_ops_parity(shdr):
+    K = shdr._ops
+    rng = np.random.default_rng(11)
+    x = f32(rng.random((2, 6, 5, 3)) * 1.4 - 0.2)
+    np.testing.assert_array_equal(host(K.clip(dev(x), 0.0, 1.0)), np.clip(x, 0, 1))
+    np.testing.assert_array_equal(host(K.reverse3(dev(x))), x[..., ::-1])
+    np.testing.assert_allclose(host(K.vgg_preprocess(dev(x))), ops.vgg_preprocess(x.astype(np.float64)), rtol=1e-6, atol=1e-4)
+    xp = np.abs(x)
+    np.testing.assert_allclose(host(K.logc(dev(xp))), ops.log_compress(xp.astype(np.float64)), atol=1e-6)
+    b = f32(rng.random((2, 6, 5, 3)))
+    b[0, 0, 0] = [1.0, 0.2, 0.3]
+    b[0, 0, 1] = [0.9, 0.95, 0.1]
+    hal = f32(rng.random((2, 6, 5, 3)))
+    a, alpha = K.alpha_blend(dev(b), dev(hal), 0.12, return_alpha=True)
+    np.testing.assert_allclose(host(a), ops.alpha_blend(b.astype(np.float64), hal.astype(np.float64)), atol=1e-6)
+    np.testing.assert_allclose(host(alpha), ops.alpha_mask(b.astype(np.float64))[..., :1], atol=1e-5)
+    p = host(K.pack3([dev(x), dev(b), dev(hal)]))
+    np.testing.assert_array_equal(p, np.concatenate([x, b, hal], -1))
+    p12 = host(K.pack3([dev(x), dev(b), dev(hal)], 12))
+    np.testing.assert_array_equal(p12[..., :9], p)
+    assert float(np.abs(p12[..., 9:]).max()) == 0
