@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
     return ap.parse_args()
 
 
@@ -55,9 +56,13 @@ def randomise_bn(model, gen):
                 t.copy_(torch.randn(t.shape, generator=gen) * 0.05)
 
 
-def conv_flops(x, w, stride):
+def conv_flops(x, w, stride, cout_valid=None):
+    """Algorithmic FLOPs 2*Ho*Wo*Cin*Cout*kh*kw of the REFERENCE layer: zero-padded filter
+    channels (Cin 3->4, 9->12, 93->96; Cout 3->16) are not counted."""
     n, h, wd, _ = x.shape
     kh, kw, cin, cout = w.shape
+    cout = cout_valid or cout
+    cin = {4: 3, 12: 9, 96: 93}.get(cin, cin)
     ho, wo = -(-h // stride), -(-wd // stride)
     return 2.0 * n * ho * wo * cin * cout * kh * kw
 
@@ -67,11 +72,11 @@ def conv_variant(w, x, x2, algo):
     c1 = x.shape[3]
     c2 = 0 if x2 is None else x2.shape[3]
     cout = w.shape[3]
-    mfma_ok = c1 % 4 == 0 and c2 % 4 == 0 and cout % 16 == 0 and (c1 + c2) >= 12
+    mfma_ok = c1 % 4 == 0 and c2 % 4 == 0 and cout % 16 == 0
     if algo == 2 or (algo == 0 and not mfma_ok):
         return "conv_direct_kernel"
     bn = 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
-    return "conv_mfma_kernel<128,%d>" % bn
+    return "conv_mfma_dma_kernel<128,%d>" % bn
 
 
 def main():
@@ -143,7 +148,9 @@ def main():
             e0.record()
             y = orig(x, w, bias, stride=stride, x2=x2, **kw)
             e1.record()
-            records.append((conv_variant(w, x, x2, kw.get("algo", 0)), conv_flops(x, w, stride), e0, e1))
+            records.append((conv_variant(w, x, x2, kw.get("algo", 0)), conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
+                            "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
+                                                        0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride)))
             return y
 
         reps = 3
@@ -155,7 +162,11 @@ def main():
         finally:
             K.conv2d = orig
         agg = {}
-        for var, fl, e0, e1 in records:
+        if args.layers:
+            for var, fl, e0, e1, desc in records[:len(records) // reps]:
+                ms = e0.elapsed_time(e1)
+                print("%-28s %-28s %8.3f ms %7.2f TF" % (var, desc, ms, fl / ms / 1e9), file=sys.stderr)
+        for var, fl, e0, e1, _ in records:
             a = agg.setdefault(var, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -184,7 +195,7 @@ def main():
         params = {k: {n: t.cpu().numpy() for n, t in m.state_dict().items()}
                   for k, m in (("deq", deq), ("lin", lin), ("hal", hal))}
         sample = ldr[:1].cpu().numpy()
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         torch.set_num_threads(cores)
         t0 = time.perf_counter()
         ref = nets.inference(params, sample, table, with_refinement=False)["A_pred"]

@@ -42,6 +42,8 @@ extern "C" {
 #define SHDR_ALGO_AUTO    0
 #define SHDR_ALGO_MFMA    1  /* fp32-MFMA implicit GEMM (needs (C1+C2)%4==0, Cout%16==0) */
 #define SHDR_ALGO_DIRECT  2  /* VALU direct convolution (any shape)                     */
+#define SHDR_ALGO_MFMA_REG 3 /* MFMA kernel with register-staged LDS fill (the LDS-DMA  */
+                             /* variant is preferred whenever x2_scale == 1)           */
 
 const char* shdr_last_error(void);
 /* library / code-object version string, e.g. "libshdr 0.1 gfx950" */
@@ -62,7 +64,7 @@ int shdr_same_pad(int in_size, int k, int stride, int* out_size, int* pad_before
  *   vgg16.py:33-35
  *
  * Input  = channel-concat [x1 (C1 ch), x2_scale * x2 (C2 ch)]   (x2 may be NULL, C2 = 0)
- * y[n,oh,ow,co] = act2( affine( act1( conv + bias ) ) + residual )
+ * y[n,oh,ow,co] = act2( affine( act1( conv + bias ) ) + residual ),  co < cout_valid
  *   affine(v) = v*scale[co] + shift[co]      (folded inference BN; scale==NULL -> identity)
  *   residual  = res[n,oh,ow,co] read with channel stride res_cstride (NULL -> 0)
  */
@@ -76,8 +78,11 @@ typedef struct shdr_conv2d_desc {
   float   x2_scale;         /* multiplier applied to x2 (hallucination_net.py:101) */
   int32_t act1, act2;       /* SHDR_ACT_*                                        */
   int32_t res_cstride;      /* channels per pixel of the residual tensor         */
-  int32_t y_cstride;        /* channels per pixel of y (>= Cout; 0 -> Cout)      */
+  int32_t y_cstride;        /* channels per pixel of y (0 -> cout_valid)          */
   int32_t algo;             /* SHDR_ALGO_*                                       */
+  int32_t cout_valid;       /* channels stored to y (0 -> Cout).  Cout may be a  */
+                            /* zero-padded filter width (multiple of 16) so that */
+                            /* e.g. a 3-channel head runs on the MFMA tile       */
 } shdr_conv2d_desc;
 
 int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
@@ -124,8 +129,10 @@ int shdr_apply_rf_fwd_f32(const float* x, const float* rf, float* y, int B,
 /* Elementwise glue of the step closures ---------------------------------- */
 /* tf.clip_by_value (test_real_refinement.py:91). */
 int shdr_clip_fwd_f32(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
-/* x*255, RGB->BGR, subtract VGG mean (hallucination_net.py:149-153, vgg16.py:101-109). */
-int shdr_vgg_preprocess_fwd_f32(const float* x, float* y, int64_t npix, void* stream);
+/* x*255, RGB->BGR, subtract VGG mean (hallucination_net.py:149-153, vgg16.py:101-109).
+ * x [npix,3] -> y [npix,out_channels], out_channels 3 or 4 (4: zero 4th channel). */
+int shdr_vgg_preprocess_fwd_f32(const float* x, float* y, int64_t npix, int out_channels,
+                                void* stream);
 /* channel reversal of 3-channel pixels (tf_utils.py:5-13). */
 int shdr_reverse3_fwd_f32(const float* x, float* y, int64_t npix, void* stream);
 /* alpha = clamp((max_c b - 1 + thr)/thr, 0, 1); a = b + alpha * reverse3(hal)

@@ -106,15 +106,35 @@ class Conv2D(Layer):
         self.bias = self.add_weight("bias", torch.zeros(filters, device=device)) if use_bias else None
         self._padded = None  # (version, cin_pad, tensor)
 
-    def kernel_padded(self, cin_pad):
-        """Kernel zero-padded along the input-channel axis (cached per parameter version)."""
-        ver = self.kernel._version
-        if self._padded is None or self._padded[0] != ver or self._padded[1] != cin_pad:
-            k = self.kernel.detach()
-            pad = torch.zeros((k.shape[0], k.shape[1], cin_pad, k.shape[3]), device=k.device, dtype=k.dtype)
-            pad[:, :, :k.shape[2], :] = k
-            self._padded = (ver, cin_pad, pad.contiguous())
-        return self._padded[2]
+    def kernel_padded(self, cin_pad=None, cout_pad=None):
+        """Kernel zero-padded along the input- and/or output-channel axis (cached per parameter
+        version).  Padding never changes the result: extra input channels meet zero taps, extra
+        output channels are not stored (`cout_valid`)."""
+        k = self.kernel.detach()
+        cin_pad = cin_pad or k.shape[2]
+        cout_pad = cout_pad or k.shape[3]
+        key = (self.kernel._version, cin_pad, cout_pad)
+        if self._padded is None or self._padded[0] != key:
+            pad = torch.zeros((k.shape[0], k.shape[1], cin_pad, cout_pad), device=k.device, dtype=k.dtype)
+            pad[:, :, :k.shape[2], :k.shape[3]] = k
+            self._padded = (key, pad.contiguous())
+        return self._padded[1]
+
+    def kernel_x2_scaled(self, c1, scale):
+        """Kernel whose input-channel rows [c1:] are multiplied by `scale` (cached per parameter
+        version): conv(concat[x, scale*x2], W) == conv(concat[x, x2], W') -- lets the two-source
+        conv run on the LDS-DMA kernel, which cannot scale data in flight."""
+        key = (self.kernel._version, "x2", c1, float(scale))
+        if self._padded is None or self._padded[0] != key:
+            k = self.kernel.detach().clone()
+            k[:, :, c1:, :] *= scale
+            self._padded = (key, k.contiguous())
+        return self._padded[1]
+
+    def call_padded(self, x, cin_pad=None, cout_pad=None, **kw):
+        """Run on the MFMA tile with a zero-padded filter; stores only the true output channels."""
+        return K.conv2d(x, self.kernel_padded(cin_pad, cout_pad), self.bias, stride=self.strides,
+                        cout_valid=self.kernel.shape[3], **kw)
 
     def call(self, x, **kw):
         return K.conv2d(x, self.kernel, self.bias, stride=self.strides, **kw)

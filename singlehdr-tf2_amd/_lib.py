@@ -25,7 +25,7 @@ class ConvDesc(ctypes.Structure):
                 ("x2_scale", ctypes.c_float),
                 ("act1", ctypes.c_int32), ("act2", ctypes.c_int32),
                 ("res_cstride", ctypes.c_int32), ("y_cstride", ctypes.c_int32),
-                ("algo", ctypes.c_int32)]
+                ("algo", ctypes.c_int32), ("cout_valid", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/shdr.h
@@ -45,7 +45,7 @@ SIGNATURES = {
     "shdr_increase_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_apply_rf_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr]),
     "shdr_clip_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_f32, c_ptr]),
-    "shdr_vgg_preprocess_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_vgg_preprocess_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "shdr_reverse3_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
     "shdr_alpha_blend_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     "shdr_pack3_fwd_f32": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_ptr]),

@@ -15,7 +15,7 @@ except ImportError:  # package directory itself on sys.path (drop-in module layo
     import _lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT = 0, 1, 2
+ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 
 
 def same_pad(in_size, k, stride):
@@ -52,13 +52,17 @@ def _d(t):
 
 
 def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scale=None,
-           shift=None, residual=None, act2=ACT_NONE, algo=ALGO_AUTO, out=None):
-    """y = act2(affine(act1(conv(concat[x, x2_scale*x2], w) + bias)) + residual), SAME padding."""
+           shift=None, residual=None, act2=ACT_NONE, algo=ALGO_AUTO, out=None, cout_valid=None):
+    """y = act2(affine(act1(conv(concat[x, x2_scale*x2], w) + bias)) + residual), SAME padding.
+
+    `cout_valid` < w.shape[3] says the filter is zero-padded along Cout (to a multiple of 16 so
+    that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored."""
     lib = _lib.load()
     x = _chk(_d(x), "x")
     w = _chk(_d(w), "w")
     n, h, wd, c1 = x.shape
-    kh, kw, cin, cout = w.shape
+    kh, kw, cin, cout_gemm = w.shape
+    cout = cout_gemm if cout_valid is None else int(cout_valid)
     c2 = 0
     if x2 is not None:
         x2 = _chk(_d(x2), "x2")
@@ -71,7 +75,8 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     wo, pl = same_pad(wd, kw, stride)
     d = _lib.ConvDesc()
     d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
-    d.Cout, d.KH, d.KW, d.stride = cout, kh, kw, stride
+    d.Cout, d.KH, d.KW, d.stride = cout_gemm, kh, kw, stride
+    d.cout_valid = cout
     d.pad_t, d.pad_l, d.Ho, d.Wo = pt, pl, ho, wo
     d.x2_scale = float(x2_scale)
     d.act1, d.act2 = act1, act2
@@ -223,11 +228,13 @@ def _pix3(x, name):
     return x, x.numel() // 3
 
 
-def vgg_preprocess(x):
+def vgg_preprocess(x, out_channels=3):
+    """x*255, RGB->BGR, minus VGG mean; out_channels=4 appends a zero channel (MFMA-friendly)."""
     lib = _lib.load()
     x, npix = _pix3(x, "x")
-    y = torch.empty_like(x)
-    _lib.check(lib.shdr_vgg_preprocess_fwd_f32(_ptr(x), _ptr(y), npix, _stream()), "shdr_vgg_preprocess_fwd_f32")
+    y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_vgg_preprocess_fwd_f32(_ptr(x), _ptr(y), npix, out_channels, _stream()),
+               "shdr_vgg_preprocess_fwd_f32")
     return y
 
 

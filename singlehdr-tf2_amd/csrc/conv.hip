@@ -17,6 +17,8 @@
 //      cannot fill (Cin = 3/6/9, Cout = 3).
 //
 // Replaces the TF op call sites listed at shdr_conv2d_fwd_f32 in include/shdr.h.
+#include <type_traits>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -41,6 +43,8 @@ struct ConvArgs {
   int nblk_m, nblk_n;
   float x2_scale;
   int act1, act2, res_cs, y_cs;
+  int no_dma;      // force the register-staged kernel (SHDR_ALGO_MFMA_REG)
+  int cout_valid;  // channels actually stored (<= Cout; the filter may be zero-padded to Cout)
 };
 
 constexpr int BK = 32;
@@ -59,8 +63,69 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// Epilogue shared by the MFMA kernels: lane (fi, fg) holds, per 16x16 tile, 4 consecutive
+// couts (4*fg..4*fg+3) of pixel fi.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int img, int oh0,
+                                              int ow0, int n0, int wm, int wn, int fi, int fg) {
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int r = wm * MT * 16 + mi * 16 + fi;
+    const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
+    if (oh >= a.Ho || ow >= a.Wo) continue;
+    const long pix = ((long)img * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int co = n0 + wn * NT * 16 + ni * 16 + 4 * fg;
+      if (co >= a.cout_valid) continue;
+      f32x4 v = acc[mi][ni];
+      if (co + 4 <= a.cout_valid) {
+        if (a.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (a.act1 != SHDR_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
+        }
+        if (a.scale) {
+          const float4 s4 = *reinterpret_cast<const float4*>(a.scale + co);
+          const float4 t4 = *reinterpret_cast<const float4*>(a.shift + co);
+          v[0] = v[0] * s4.x + t4.x; v[1] = v[1] * s4.y + t4.y;
+          v[2] = v[2] * s4.z + t4.z; v[3] = v[3] * s4.w + t4.w;
+        }
+        if (a.res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(a.res + (size_t)pix * a.res_cs + co);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (a.act2 != SHDR_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
+        }
+        *reinterpret_cast<float4*>(a.y + (size_t)pix * a.y_cs + co) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {  // ragged tail of a zero-padded filter (e.g. Cout = 3): scalar, unaligned-safe
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (co + e >= a.cout_valid) break;
+          float t = v[e];
+          if (a.bias) t += a.bias[co + e];
+          t = shdr::act_apply(t, a.act1);
+          if (a.scale) t = t * a.scale[co + e] + a.shift[co + e];
+          if (a.res) t += a.res[(size_t)pix * a.res_cs + co + e];
+          t = shdr::act_apply(t, a.act2);
+          a.y[(size_t)pix * a.y_cs + co + e] = t;
+        }
+      }
+    }
+  }
+}
+
+// FAST: (C1+C2) % 32 == 0 and the two sources split on a 32-channel boundary, so the tap,
+// the channel chunk and the source of a k-chunk are wave-uniform scalars and chunks run
+// channel-chunk-outer / tap-inner (the taps of one 128-byte channel slice re-hit L1/L2).
+// !FAST: natural k order with per-thread (tap, channel) state; any C1 % 4 == C2 % 4 == 0.
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TH = BM / 16;          // pixel tile = TH rows x 16 columns
   constexpr int MT = BM / WM / 16;     // 16-pixel groups per wave
@@ -70,6 +135,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int BQ = BN / 4;           // quads per B row
   constexpr int BROWS_PER_PASS = 256 / BQ;
   constexpr int BPASS = (BK + BROWS_PER_PASS - 1) / BROWS_PER_PASS;
+  constexpr int KSTEPS = BK / 4;
+  constexpr bool BFULL = (BROWS_PER_PASS * BPASS == BK);  // every thread's B rows are inside the chunk
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][SA]
@@ -90,10 +157,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int n0 = pn * BN;
   const int oh0 = ty * TH, ow0 = tx * 16;
 
-  // ---- per-thread A-load geometry (fixed over the K loop) -----------------
+  // ---- per-thread load geometry, fixed over the K loop ----------------------
   const int aj = tid & 7;    // quad slot inside the 32-channel chunk
   const int ar0 = tid >> 3;  // 0..31
   int ihb[AROWS], iwb[AROWS];
+  unsigned rowoff1[AROWS], rowoff2[AROWS];  // element offset of (pixel, channel 0) in x1 / x2
+  const unsigned img_base = (unsigned)img * (unsigned)(a.H * a.W);
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int r = ar0 + 32 * i;
@@ -101,50 +170,71 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const bool ok = (oh < a.Ho) && (ow < a.Wo);
     ihb[i] = ok ? oh * a.stride - a.pad_t : -(1 << 28);
     iwb[i] = ow * a.stride - a.pad_l;
+    const unsigned pix = ok ? img_base + (unsigned)(ihb[i] * a.W + iwb[i]) : 0u;  // may wrap for taps < 0: only used when in bounds
+    rowoff1[i] = pix * (unsigned)a.C1;
+    rowoff2[i] = pix * (unsigned)a.C2;
   }
   const int bq = tid % BQ, bk0 = tid / BQ;
-  const long img_base = (long)img * a.H * a.W;
+  unsigned wrow[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) wrow[i] = (unsigned)(bk0 + BROWS_PER_PASS * i) * (unsigned)a.Cout + (unsigned)(n0 + 4 * bq);
 
+  // Register staging of the next chunk: unconditional loads from clamped addresses issue
+  // back to back; validity and the x2 scale are applied when the registers go to LDS.
   float4 areg[AROWS];
   float4 breg[BPASS];
-
-  auto load_chunk = [&](int kc) {
-    int tap, c, krow0;
-    bool kvalid = true;
-    if (a.chunked) {
-      tap = kc % a.ntaps;
-      const int c0 = (kc / a.ntaps) * BK;
-      c = c0 + 4 * aj;
-      krow0 = tap * a.Ct + c0;
-    } else {
-      const int kflat = kc * BK + 4 * aj;
-      tap = kflat / a.Ct;
-      c = kflat - tap * a.Ct;
-      kvalid = kflat < a.K;
-      krow0 = kc * BK;
+  bool aok[AROWS], bok[BPASS];
+  float ascale = 1.0f;
+  // position of the next chunk: scalars when FAST, per-thread otherwise
+  int nx_kh = 0, nx_kw = 0, nx_c = FAST ? 0 : 4 * aj, nx_kc = 0;
+  if (!FAST) {  // Ct < 32: the first chunk already spans several taps
+    while (nx_c >= a.Ct && nx_kh < a.KH) {
+      nx_c -= a.Ct;
+      if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
     }
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const float* src = a.x1;
-    int cs = a.C1, cc = c;
-    float sc = 1.0f;
-    if (c >= a.C1) { src = a.x2; cs = a.C2; cc = c - a.C1; sc = a.x2_scale; }
+  }
+
+  auto load_next = [&]() {
+    const int kh = nx_kh, kw = nx_kw;
+    bool kvalid, second;
+    unsigned krow0;
+    int cc;
+    if (FAST) {
+      kvalid = true;
+      second = nx_c >= a.C1;                          // uniform
+      cc = (second ? nx_c - a.C1 : nx_c) + 4 * aj;
+      krow0 = (unsigned)((kh * a.KW + kw) * a.Ct + nx_c);
+      if (++nx_kw == a.KW) {
+        nx_kw = 0;
+        if (++nx_kh == a.KH) { nx_kh = 0; nx_c += BK; }
+      }
+    } else {
+      kvalid = kh < a.KH;
+      second = kvalid && (nx_c >= a.C1);
+      cc = kvalid ? (second ? nx_c - a.C1 : nx_c) : 0;
+      krow0 = (unsigned)(nx_kc * BK);
+      nx_c += BK;                                      // advance my quad by 32 k positions
+      while (nx_c >= a.Ct && nx_kh < a.KH) {
+        nx_c -= a.Ct;
+        if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
+      }
+    }
+    ++nx_kc;
+    const float* src = second ? a.x2 : a.x1;
+    const unsigned delta = (unsigned)((kh * a.W + kw) * (second ? a.C2 : a.C1) + cc);
+    ascale = second ? a.x2_scale : 1.0f;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int ih = ihb[i] + kh, iw = iwb[i] + kw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
-        v = *reinterpret_cast<const float4*>(src + ((img_base + (long)ih * a.W + iw) * cs + cc));
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-      }
-      areg[i] = v;
+      aok[i] = kvalid && (unsigned)(ihb[i] + kh) < (unsigned)a.H && (unsigned)(iwb[i] + kw) < (unsigned)a.W;
+      const unsigned off = aok[i] ? (second ? rowoff2[i] : rowoff1[i]) + delta : 0u;
+      areg[i] = *reinterpret_cast<const float4*>(src + (size_t)off);
     }
+    const unsigned wbase = krow0 * (unsigned)a.Cout;
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       const int bk = bk0 + BROWS_PER_PASS * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bk < BK && (krow0 + bk) < a.K)
-        v = *reinterpret_cast<const float4*>(a.w + ((long)(krow0 + bk) * a.Cout + n0 + 4 * bq));
-      breg[i] = v;
+      bok[i] = (BFULL || bk < BK) && (FAST || (int)krow0 + bk < a.K);
+      breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)(bok[i] ? wbase + wrow[i] : 0u));
     }
   };
 
@@ -154,13 +244,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       float* p = Ab + (ar0 + 32 * i) * SA + 4 * aj;
-      *reinterpret_cast<float2*>(p) = make_float2(areg[i].x, areg[i].y);
-      *reinterpret_cast<float2*>(p + 2) = make_float2(areg[i].z, areg[i].w);
+      const float4 v = areg[i];
+      *reinterpret_cast<float2*>(p) = aok[i] ? make_float2(v.x * ascale, v.y * ascale) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(p + 2) = aok[i] ? make_float2(v.z * ascale, v.w * ascale) : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       const int bk = bk0 + BROWS_PER_PASS * i;
-      if (bk < BK) *reinterpret_cast<float4*>(Bb + bk * SB + 4 * bq) = breg[i];
+      if (BFULL || bk < BK)
+        *reinterpret_cast<float4*>(Bb + bk * SB + 4 * bq) = bok[i] ? breg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
 
@@ -174,69 +266,269 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int a_off = (wm * MT * 16 + fi) * SA + fg;   // + mi*16*SA + 4*s
   const int b_off = fg * SB + wn * NT * 16 + fi;     // + 4*s*SB + ni*16
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int kc = 0; kc < a.nchunks; ++kc) {
-    const int buf = kc & 1;
-    const bool more = (kc + 1) < a.nchunks;
-    if (more) load_chunk(kc + 1);
+  // One k-chunk of MFMAs on LDS buffer `buf`.  WITH_NEXT: the next chunk's global loads are
+  // issued in the shadow of k-step 0's MFMAs and written to the other LDS buffer in the
+  // shadow of k-step KSTEPS-2's, so the loop body is straight-line code.
+  auto compute_chunk = [&](int buf, auto with_next) {
+    constexpr bool WITH_NEXT = decltype(with_next)::value;
     const float* Ab = As + buf * BM * SA + a_off;
     const float* Bb = Bs + buf * BK * SB + b_off;
+    float af[2][MT], bf[2][NT];
 #pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      float af[MT], bf[NT];
+    for (int mi = 0; mi < MT; ++mi) af[0][mi] = Ab[mi * 16 * SA];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) af[mi] = Ab[mi * 16 * SA + 4 * s];
+    for (int ni = 0; ni < NT; ++ni) bf[0][ni] = Bb[ni * 16];
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) bf[ni] = Bb[4 * s * SB + ni * 16];
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < KSTEPS) {  // fragments of k-step s+1 are in flight while step s runs on the matrix pipe
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) af[cur ^ 1][mi] = Ab[mi * 16 * SA + 4 * (s + 1)];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bf[cur ^ 1][ni] = Bb[4 * (s + 1) * SB + ni * 16];
+      }
+      if constexpr (WITH_NEXT) {
+        if (s == 1) load_next();
+        if (s == KSTEPS - 1) store_chunk(buf ^ 1);
+      }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][ni], af[cur][mi], acc[mi][ni], 0, 0, 0);
     }
-    if (more) store_chunk(buf ^ 1);
+  };
+
+  load_next();
+  store_chunk(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int kc = 0; kc + 1 < a.nchunks; ++kc) {
+    compute_chunk(kc & 1, std::true_type{});
     __syncthreads();
   }
+  compute_chunk((a.nchunks - 1) & 1, std::false_type{});
 
-  // ---- epilogue: lane holds 4 consecutive couts of one pixel ---------------
+  conv_epilogue<MT, NT>(a, acc, img, oh0, ow0, n0, wm, wn, fi, fg);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA variant (global_load_lds_dwordx4): the k-chunk goes HBM/L2 -> LDS with no
+// register staging, no ds_write and no per-element select.
+//   * LDS images are lane-linear (a wave instruction writes 1 KiB in lane order), so the
+//     bank-conflict swizzle is applied on the SOURCE side:
+//       A  [BM rows][8 quads]: physical quad slot p of row r holds logical quad p ^ ((r>>1)&7);
+//          fragments are read with ds_read_b128 (conflict-free for the 16-lane b128 groups);
+//          lane group g owns k = {4g..4g+3, 16+4g..16+4g+3} of the chunk (any k permutation is
+//          legal as long as A and B agree).
+//       B  [32 rows][BN]: physical column = n ^ (16 * ((k>>2)&1))  (BN >= 32) -> the two k rows
+//          of a half-wave hit disjoint 16-bank halves.
+//   * padding / K tail: invalid quads read from a 16-byte zero page.
+//   * needs x2_scale == 1 (the host pre-scales the x2 rows of the filter instead).
+// ---------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(1))) const void* shdr_gptr_t;
+typedef __attribute__((address_space(3))) void* shdr_lptr_t;
+
+template <int BM, int BN>
+__host__ __device__ constexpr int conv_dma_lds_bytes() { return 2 * (BM * BK + BK * BN) * 4; }
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int TH = BM / 16;
+  constexpr int MT = BM / WM / 16;
+  constexpr int NT = BN / WN / 16;
+  constexpr int KSTEPS = BK / 4;
+  constexpr int AI = BM / 32;                      // A DMA instructions per wave per chunk (8 rows each)
+  constexpr int BQ = BN / 4;                       // quads per B row
+  constexpr int BI = (BK * BQ / 64 + 3) / 4;       // B DMA instructions per wave per chunk
+  constexpr int B_WAVES = (BK * BQ / 64) >= 4 ? 4 : (BK * BQ / 64);  // waves that carry B (BN = 16: 2)
+  constexpr bool BSWZ = BN >= 32;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BM][32]
+  float* Bs = smem + 2 * BM * BK;    // [2][32][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int L = xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
+  const int pn = L % a.nblk_n;
+  int pm = L / a.nblk_n;
+  const int tx = pm % a.tiles_x;
+  pm /= a.tiles_x;
+  const int ty = pm % a.tiles_y;
+  const int img = pm / a.tiles_y;
+  const int n0 = pn * BN;
+  const int oh0 = ty * TH, ow0 = tx * 16;
+  const float* zero = g_zero_page;
+
+  // ---- A geometry: instruction i of this wave fills rows (wave*AI + i)*8 .. +7 -------------
+  int ihb[AI], iwb[AI], aq[AI];
+  unsigned rowoff1[AI], rowoff2[AI];
+  const unsigned img_base = (unsigned)img * (unsigned)(a.H * a.W);
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const int r = wm * MT * 16 + mi * 16 + fi;
+  for (int i = 0; i < AI; ++i) {
+    const int r = (wave * AI + i) * 8 + (lane >> 3);
+    aq[i] = (lane & 7) ^ ((r >> 1) & 7);            // logical quad fetched into physical slot lane&7
     const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
-    if (oh >= a.Ho || ow >= a.Wo) continue;
-    const long pix = ((long)img * a.Ho + oh) * a.Wo + ow;
+    const bool ok = (oh < a.Ho) && (ow < a.Wo);
+    ihb[i] = ok ? oh * a.stride - a.pad_t : -(1 << 28);
+    iwb[i] = ow * a.stride - a.pad_l;
+    const unsigned pix = ok ? img_base + (unsigned)(ihb[i] * a.W + iwb[i]) : 0u;
+    rowoff1[i] = pix * (unsigned)a.C1 + (FAST ? 4u * (unsigned)aq[i] : 0u);
+    rowoff2[i] = pix * (unsigned)a.C2 + (FAST ? 4u * (unsigned)aq[i] : 0u);
+  }
+  // ---- B geometry ----------------------------------------------------------------------------
+  unsigned woff[BI];
+  int wk[BI];
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      const int co = n0 + wn * NT * 16 + ni * 16 + 4 * fg;
-      f32x4 v = acc[mi][ni];
-      if (a.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      if (a.act1 != SHDR_ACT_NONE) {
+  for (int j = 0; j < BI; ++j) {
+    const int Q = (wave * BI + j) * 64 + lane;     // linear quad index inside the B tile
+    const int k = Q / BQ, pq = Q % BQ;
+    const int lq = BSWZ ? (pq ^ (4 * ((k >> 2) & 1))) : pq;
+    wk[j] = k;
+    woff[j] = (unsigned)k * (unsigned)a.Cout + (unsigned)(n0 + 4 * lq);
+  }
+
+  // position of the next chunk: scalars when FAST; per-instruction (tap, channel) otherwise
+  int nx_kh = 0, nx_kw = 0, nx_c = 0, nx_kc = 0;
+  int t_kh[AI], t_kw[AI], t_c[AI];
+  if (!FAST) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
+    for (int i = 0; i < AI; ++i) {
+      t_kh[i] = 0; t_kw[i] = 0; t_c[i] = 4 * aq[i];
+      while (t_c[i] >= a.Ct && t_kh[i] < a.KH) {
+        t_c[i] -= a.Ct;
+        if (++t_kw[i] == a.KW) { t_kw[i] = 0; ++t_kh[i]; }
       }
-      if (a.scale) {
-        const float4 s4 = *reinterpret_cast<const float4*>(a.scale + co);
-        const float4 t4 = *reinterpret_cast<const float4*>(a.shift + co);
-        v[0] = v[0] * s4.x + t4.x; v[1] = v[1] * s4.y + t4.y;
-        v[2] = v[2] * s4.z + t4.z; v[3] = v[3] * s4.w + t4.w;
-      }
-      if (a.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(a.res + pix * a.res_cs + co);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (a.act2 != SHDR_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
-      }
-      *reinterpret_cast<float4*>(a.y + pix * a.y_cs + co) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
+
+  auto dma_next = [&](int buf) {
+    float* Ab = As + buf * BM * BK + (wave * AI) * 8 * BK;   // wave-uniform
+    float* Bb = Bs + buf * BK * BN + (wave * BI) * 256;
+    unsigned krow0;
+    if (FAST) {
+      const int kh = nx_kh, kw = nx_kw;
+      const bool second = nx_c >= a.C1;
+      const float* src = second ? a.x2 : a.x1;
+      const unsigned delta = (unsigned)((kh * a.W + kw) * (second ? a.C2 : a.C1) + (second ? nx_c - a.C1 : nx_c));
+      krow0 = (unsigned)((kh * a.KW + kw) * a.Ct + nx_c);
+      if (++nx_kw == a.KW) {
+        nx_kw = 0;
+        if (++nx_kh == a.KH) { nx_kh = 0; nx_c += BK; }
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = (unsigned)(ihb[i] + kh) < (unsigned)a.H && (unsigned)(iwb[i] + kw) < (unsigned)a.W;
+        const float* p = ok ? src + (size_t)((second ? rowoff2[i] : rowoff1[i]) + delta) : zero;
+        __builtin_amdgcn_global_load_lds((shdr_gptr_t)p, (shdr_lptr_t)(Ab + i * 8 * BK), 16, 0, 0);
+      }
+    } else {
+      krow0 = (unsigned)(nx_kc * BK);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int kh = t_kh[i], kw = t_kw[i];
+        const bool kvalid = kh < a.KH;
+        const bool second = kvalid && (t_c[i] >= a.C1);
+        const float* src = second ? a.x2 : a.x1;
+        const bool ok = kvalid && (unsigned)(ihb[i] + kh) < (unsigned)a.H && (unsigned)(iwb[i] + kw) < (unsigned)a.W;
+        const unsigned off = (second ? rowoff2[i] : rowoff1[i]) +
+                             (unsigned)((kh * a.W + kw) * (second ? a.C2 : a.C1) + (second ? t_c[i] - a.C1 : t_c[i]));
+        const float* p = ok ? src + (size_t)off : zero;
+        __builtin_amdgcn_global_load_lds((shdr_gptr_t)p, (shdr_lptr_t)(Ab + i * 8 * BK), 16, 0, 0);
+        t_c[i] += BK;
+        while (t_c[i] >= a.Ct && t_kh[i] < a.KH) {
+          t_c[i] -= a.Ct;
+          if (++t_kw[i] == a.KW) { t_kw[i] = 0; ++t_kh[i]; }
+        }
+      }
+    }
+    ++nx_kc;
+    if (wave < B_WAVES) {
+      const unsigned wbase = krow0 * (unsigned)a.Cout;
+#pragma unroll
+      for (int j = 0; j < BI; ++j) {
+        const bool ok = FAST || ((int)krow0 + wk[j] < a.K);
+        const float* p = ok ? a.w + (size_t)(wbase + woff[j]) : zero;
+        __builtin_amdgcn_global_load_lds((shdr_gptr_t)p, (shdr_lptr_t)(Bb + j * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fg = lane >> 4;
+  int a_rd[MT][2];   // dword offsets of this lane's two A quads (k = 4fg.., 16+4fg..) per 16-pixel group
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int row = wm * MT * 16 + mi * 16 + fi;
+    const int f = (row >> 1) & 7;
+    a_rd[mi][0] = row * BK + 4 * (fg ^ f);
+    a_rd[mi][1] = row * BK + 4 * ((fg + 4) ^ f);
+  }
+  int b_col[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int col = wn * NT * 16 + ni * 16 + fi;
+    b_col[ni] = BSWZ ? (col ^ (16 * (fg & 1))) : col;
+  }
+  // B row of k-step s for lane group fg: 16*(s>>2) + 4*fg + (s&3)
+  const int b_row0 = 4 * fg * BN;
+
+  auto compute_chunk = [&](int buf, auto with_next) {
+    constexpr bool WITH_NEXT = decltype(with_next)::value;
+    const float* Ab = As + buf * BM * BK;
+    const float* Bb = Bs + buf * BK * BN + b_row0;
+    float4 qa[MT][2];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) qa[mi][0] = *reinterpret_cast<const float4*>(Ab + a_rd[mi][0]);
+    float bf[2][NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) bf[0][ni] = Bb[b_col[ni]];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) qa[mi][1] = *reinterpret_cast<const float4*>(Ab + a_rd[mi][1]);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < KSTEPS) {
+        const int s1 = s + 1;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bf[cur ^ 1][ni] = Bb[(16 * (s1 >> 2) + (s1 & 3)) * BN + b_col[ni]];
+      }
+      if constexpr (WITH_NEXT) {
+        if (s == 1) dma_next(buf ^ 1);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const float4 q = qa[mi][s >> 2];
+        const float av = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][ni], av, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  dma_next(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int kc = 0; kc + 1 < a.nchunks; ++kc) {
+    compute_chunk(kc & 1, std::true_type{});
+    __syncthreads();
+  }
+  compute_chunk((a.nchunks - 1) & 1, std::false_type{});
+
+  conv_epilogue<MT, NT>(a, acc, img, oh0, ow0, n0, wm, wn, fi, fg);
 }
 
 // ---------------------------------------------------------------------------
@@ -297,8 +589,29 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_mfma(ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool FAST>
+int launch_mfma_dma_impl(ConvArgs& a, hipStream_t st) {
+  constexpr int TH = BM / 16;
+  a.tiles_x = (a.Wo + 15) / 16;
+  a.tiles_y = (a.Ho + TH - 1) / TH;
+  a.nblk_m = a.N * a.tiles_y * a.tiles_x;
+  a.nblk_n = a.Cout / BN;
+  constexpr int lds = conv_dma_lds_bytes<BM, BN>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_dma_kernel<BM, BN, WM, WN, FAST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const long nblk = (long)a.nblk_m * a.nblk_n;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d: grid of %ld blocks", nblk);
+  hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, WM, WN, FAST>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  return shdr::check_launch("conv_mfma_dma_kernel");
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+int launch_mfma_impl(ConvArgs& a, hipStream_t st) {
   constexpr int TH = BM / 16;
   a.tiles_x = (a.Wo + 15) / 16;
   a.tiles_y = (a.Ho + TH - 1) / TH;
@@ -307,15 +620,25 @@ int launch_mfma(ConvArgs& a, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<BM, BN>();
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BM, BN, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BM, BN, WM, WN, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, FAST>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_mfma_kernel");
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_mfma(ConvArgs& a, hipStream_t st) {
+  const bool fast = (a.Ct % BK == 0) && (a.C2 == 0 || a.C1 % BK == 0);
+  a.chunked = fast;
+  a.nchunks = fast ? a.ntaps * (a.Ct / BK) : (a.K + BK - 1) / BK;
+  if (a.x2_scale == 1.0f && !a.no_dma)
+    return fast ? launch_mfma_dma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_dma_impl<BM, BN, WM, WN, false>(a, st);
+  return fast ? launch_mfma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_impl<BM, BN, WM, WN, false>(a, st);
 }
 
 template <int CPT>
@@ -357,11 +680,16 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   SHDR_REQUIRE((long)(d->Ho - 1) * d->stride - d->pad_t < d->H &&
                    (long)(d->Wo - 1) * d->stride - d->pad_l < d->W,
                SHDR_E_SHAPE, "conv2d: output %dx%d too large for input %dx%d", d->Ho, d->Wo, d->H, d->W);
-  const int y_cs = d->y_cstride > 0 ? d->y_cstride : d->Cout;
-  SHDR_REQUIRE(y_cs >= d->Cout, SHDR_E_SHAPE, "conv2d: y_cstride < Cout");
-  SHDR_REQUIRE(!residual || d->res_cstride >= d->Cout, SHDR_E_SHAPE, "conv2d: res_cstride < Cout");
+  const int cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  SHDR_REQUIRE(cout_valid <= d->Cout, SHDR_E_SHAPE, "conv2d: cout_valid > Cout");
+  const int y_cs = d->y_cstride > 0 ? d->y_cstride : cout_valid;
+  SHDR_REQUIRE(y_cs >= cout_valid, SHDR_E_SHAPE, "conv2d: y_cstride < stored channels");
+  SHDR_REQUIRE(!residual || d->res_cstride >= cout_valid, SHDR_E_SHAPE, "conv2d: res_cstride < stored channels");
   SHDR_REQUIRE((long)d->N * d->H * d->W < (1L << 31) && (long)d->N * d->Ho * d->Wo < (1L << 31),
                SHDR_E_SHAPE, "conv2d: more than 2^31 pixels");
+  SHDR_REQUIRE((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) < (1L << 32) &&
+                   (long)d->KH * d->KW * (d->C1 + d->C2) * d->Cout < (1L << 32),
+               SHDR_E_SHAPE, "conv2d: tensor with more than 2^32 elements");
 
   ConvArgs a{};
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift;
@@ -375,16 +703,18 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   a.nchunks = a.chunked ? a.ntaps * (a.Ct / BK) : (a.K + BK - 1) / BK;
   a.x2_scale = d->C2 > 0 ? d->x2_scale : 1.0f;
   a.act1 = d->act1; a.act2 = d->act2;
-  a.res_cs = d->res_cstride; a.y_cs = y_cs;
+  a.res_cs = d->res_cstride; a.y_cs = y_cs; a.cout_valid = cout_valid;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-  const bool mfma_ok = (a.C1 % 4 == 0) && (a.C2 % 4 == 0) && (a.Cout % 16 == 0) && (y_cs % 4 == 0) &&
-                       (!residual || d->res_cstride % 4 == 0) && shdr::aligned16(x1) &&
+  const bool ragged = (cout_valid % 4) != 0;  // scalar epilogue: no alignment demands on y/res/bias
+  const bool mfma_ok = (a.C1 % 4 == 0) && (a.C2 % 4 == 0) && (a.Cout % 16 == 0) &&
+                       (ragged || ((y_cs % 4 == 0) && (!residual || d->res_cstride % 4 == 0))) && shdr::aligned16(x1) &&
                        (!x2 || shdr::aligned16(x2)) && shdr::aligned16(w) && shdr::aligned16(y) &&
                        (!bias || shdr::aligned16(bias)) && (!scale || shdr::aligned16(scale)) &&
                        (!shift || shdr::aligned16(shift)) && (!residual || shdr::aligned16(residual));
   int algo = d->algo;
-  if (algo == SHDR_ALGO_AUTO) algo = (mfma_ok && a.Ct >= 12) ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
+  if (algo == SHDR_ALGO_AUTO) algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
+  if (algo == SHDR_ALGO_MFMA_REG) { a.no_dma = 1; algo = SHDR_ALGO_MFMA; }
   if (algo == SHDR_ALGO_MFMA) {
     SHDR_REQUIRE(mfma_ok, SHDR_E_ALIGN,
                  "conv2d: MFMA path needs C1%%4==0, C2%%4==0, Cout%%16==0, 16-byte aligned tensors");
@@ -394,6 +724,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
     return launch_mfma<128, 16, 4, 1>(a, st);
   }
   if (algo == SHDR_ALGO_DIRECT) {
+    SHDR_REQUIRE(cout_valid == a.Cout, SHDR_E_SHAPE, "conv2d: direct path does not take padded filters");
     if (a.Cout <= 3) return launch_direct<3>(a, st);
     if (a.Cout % 16 == 0) return launch_direct<16>(a, st);
     return launch_direct<8>(a, st);

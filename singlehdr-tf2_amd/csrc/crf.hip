@@ -53,24 +53,22 @@ __global__ __launch_bounds__(256) void invcrf_decode_kernel(const float* __restr
   }
 }
 
-// one block (256 threads) per batch row, K <= 4096.  Each thread owns EPT
-// consecutive gradient samples so that the prefix sum is a serial scan inside
-// a thread + a wave scan + a 4-wave carry.
-template <int EPT>
+// one block (256 threads) per batch row, K <= 4096.  min / sum are block reductions; the
+// prefix sum itself is run sequentially by one thread in the reference's (TF-CPU cumsum)
+// order: fp32 addition is monotone, so with g >= 0 the CDF is non-decreasing bit for bit,
+// which a tree scan does not guarantee.  1023 dependent adds ~ 2 us; one block per image.
 __global__ __launch_bounds__(256) void increase_kernel(const float* __restrict__ rf,
                                                        float* __restrict__ out, int K) {
+  extern __shared__ float g[];  // K - 1 gradients, reused for the running sum
   __shared__ float sred[4];
-  __shared__ float sbase[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* r = rf + (long)b * K;
-  const int G = K - 1;  // number of forward differences
-  float g[EPT];
+  const int G = K - 1;
   float mn = __builtin_huge_valf();
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int k = tid * EPT + e;
-    g[e] = k < G ? r[k + 1] - r[k] : 0.f;
-    if (k < G) mn = fminf(mn, g[e]);
+  for (int k = tid; k < G; k += 256) {
+    const float d = r[k + 1] - r[k];
+    g[k] = d;
+    mn = fminf(mn, d);
   }
   mn = wave_min(mn);
   if (lane == 0) sred[wave] = mn;
@@ -79,48 +77,28 @@ __global__ __launch_bounds__(256) void increase_kernel(const float* __restrict__
   const float rr = fmaxf(-mn, 0.f);
   __syncthreads();
   float loc = 0.f;
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int k = tid * EPT + e;
-    g[e] = k < G ? g[e] + rr : 0.f;
-    loc += g[e];
+  for (int k = tid; k < G; k += 256) {
+    const float v = g[k] + rr;
+    g[k] = v;
+    loc += v;
   }
-  const float tot_w = wave_sum(loc);
-  if (lane == 0) sred[wave] = tot_w;
+  loc = wave_sum(loc);
+  if (lane == 0) sred[wave] = loc;
   __syncthreads();
   const float total = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-  __syncthreads();
-  // normalise, then inclusive scan of the normalised gradient
-  loc = 0.f;
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    g[e] = g[e] / total;
-    loc += g[e];
-    g[e] = loc;  // running sum inside the thread
-  }
-  float incl = loc;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) sred[wave] = incl;
+  for (int k = tid; k < G; k += 256) g[k] = g[k] / total;
   __syncthreads();
   if (tid == 0) {
-    sbase[0] = 0.f;
-    sbase[1] = sred[0];
-    sbase[2] = sred[0] + sred[1];
-    sbase[3] = (sred[0] + sred[1]) + sred[2];
+    float run = 0.f;
+    for (int k = 0; k < G; ++k) {
+      run += g[k];
+      g[k] = run;
+    }
   }
   __syncthreads();
-  const float base = sbase[wave] + (incl - loc);
   float* o = out + (long)b * K;
   if (tid == 0) o[0] = 0.f;
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int k = tid * EPT + e;
-    if (k < G) o[k + 1] = base + g[e];
-  }
+  for (int k = tid; k < G; k += 256) o[k + 1] = g[k];
 }
 
 // grid (blocks_x, B): the batch row's LUT lives in LDS (K*4 bytes).
@@ -172,8 +150,7 @@ extern "C" int shdr_increase_fwd_f32(const float* rf, float* out, int B, int K, 
   SHDR_REQUIRE(rf && out, SHDR_E_NULL, "increase: null pointer");
   SHDR_REQUIRE(B > 0 && K >= 2 && K <= 4096, SHDR_E_SHAPE, "increase: need B>0 and 2 <= K <= 4096 (K=%d)", K);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (K - 1 <= 256 * 4) hipLaunchKernelGGL(increase_kernel<4>, dim3(B), dim3(256), 0, st, rf, out, K);
-  else hipLaunchKernelGGL(increase_kernel<16>, dim3(B), dim3(256), 0, st, rf, out, K);
+  hipLaunchKernelGGL(increase_kernel, dim3(B), dim3(256), (size_t)(K - 1) * sizeof(float), st, rf, out, K);
   return shdr::check_launch("increase");
 }
 

@@ -27,12 +27,15 @@ __global__ __launch_bounds__(256) void logc_kernel(const float* __restrict__ x, 
 
 // 3-channel pixels: one thread per pixel.
 __global__ __launch_bounds__(256) void vgg_preprocess_kernel(const float* __restrict__ x,
-                                                             float* __restrict__ y, long npix) {
+                                                             float* __restrict__ y, long npix, int oc) {
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
     const float r = x[3 * p], g = x[3 * p + 1], b = x[3 * p + 2];
-    y[3 * p] = b * 255.0f - kVggMean0;
-    y[3 * p + 1] = g * 255.0f - kVggMean1;
-    y[3 * p + 2] = r * 255.0f - kVggMean2;
+    const float v0 = b * 255.0f - kVggMean0, v1 = g * 255.0f - kVggMean1, v2 = r * 255.0f - kVggMean2;
+    if (oc == 4) {
+      *reinterpret_cast<float4*>(y + 4 * p) = make_float4(v0, v1, v2, 0.0f);
+    } else {
+      y[3 * p] = v0; y[3 * p + 1] = v1; y[3 * p + 2] = v2;
+    }
   }
 }
 
@@ -97,11 +100,14 @@ extern "C" int shdr_logc_fwd_f32(const float* x, float* y, int64_t n, void* stre
   return shdr::check_launch("logc");
 }
 
-extern "C" int shdr_vgg_preprocess_fwd_f32(const float* x, float* y, int64_t npix, void* stream) {
+extern "C" int shdr_vgg_preprocess_fwd_f32(const float* x, float* y, int64_t npix, int out_channels,
+                                           void* stream) {
   SHDR_REQUIRE(x && y, SHDR_E_NULL, "vgg_preprocess: null pointer");
   SHDR_REQUIRE(npix > 0, SHDR_E_SHAPE, "vgg_preprocess: npix must be positive");
+  SHDR_REQUIRE(out_channels == 3 || out_channels == 4, SHDR_E_SHAPE, "vgg_preprocess: out_channels must be 3 or 4");
+  SHDR_REQUIRE(out_channels == 3 || shdr::aligned16(y), SHDR_E_ALIGN, "vgg_preprocess: y not 16-byte aligned");
   hipLaunchKernelGGL(vgg_preprocess_kernel, dim3(shdr::stream_grid(npix)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, y, (long)npix);
+                     reinterpret_cast<hipStream_t>(stream), x, y, (long)npix, out_channels);
   return shdr::check_launch("vgg_preprocess");
 }
 

@@ -59,7 +59,13 @@ class _unet(Layer):
         self.out = Conv2D(16, 3, (3, 3), device=device)
 
     def _trunk(self, input_images):
-        x = self.conv1(input_images, act1=K.ACT_LRELU)
+        cin = input_images.shape[-1]
+        if cin == 3:      # 3 -> 4 channels (zero) so that the 7x7 conv runs on the MFMA tile
+            x = self.conv1.call_padded(K.pack3([input_images], 4), cin_pad=4, act1=K.ACT_LRELU)
+        elif cin % 4 == 0 and cin != self.conv1.kernel.shape[2]:   # caller passed a zero-padded input
+            x = self.conv1.call_padded(input_images, cin_pad=cin, act1=K.ACT_LRELU)
+        else:
+            x = self.conv1(input_images, act1=K.ACT_LRELU)
         s1 = self.conv2(x, act1=K.ACT_LRELU)
         s2 = self.d2(s1)
         s3 = self.d3(s2)
@@ -78,4 +84,4 @@ class model(_unet):
     def call(self, input_images, training="training"):
         x = self._trunk(input_images)
         # tanh(out(x)) + input  (dequantization_net.py:62-63) fused into the conv epilogue
-        return self.out(x, act1=K.ACT_TANH, residual=input_images)
+        return self.out.call_padded(x, cout_pad=16, act1=K.ACT_TANH, residual=input_images)

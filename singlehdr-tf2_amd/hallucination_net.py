@@ -30,7 +30,10 @@ class down1(Layer):
         self.conv2 = Conv2D(outChannels, outChannels, (3, 3), device=device)
 
     def call(self, x):
-        x = self.conv1(x, act1=K.ACT_RELU)
+        if x.shape[-1] != self.conv1.kernel.shape[2]:   # zero-padded input (3 -> 4 channels)
+            x = self.conv1.call_padded(x, cin_pad=x.shape[-1], act1=K.ACT_RELU)
+        else:
+            x = self.conv1(x, act1=K.ACT_RELU)
         skip_layer = self.conv2(x, act1=K.ACT_RELU)
         return K.maxpool2(skip_layer), skip_layer
 
@@ -75,6 +78,10 @@ class skipLayer(Layer):
         self.conv1 = Conv2D(xChannels + skChannels, outChannels, (1, 1), device=device)
 
     def call(self, x, sk, **kw):
+        c1 = x.shape[-1]
+        if c1 % 4 == 0 and sk.shape[-1] % 4 == 0:
+            # fold the 1/255 into the sk rows of the filter (cached) -> LDS-DMA conv kernel
+            return K.conv2d(x, self.conv1.kernel_x2_scaled(c1, 1.0 / 255), self.conv1.bias, x2=sk, **kw)
         return self.conv1(x, x2=sk, x2_scale=1.0 / 255, **kw)
 
 
@@ -108,7 +115,7 @@ class model(Layer):
         if list(self.VGG_MEAN) != [103.939, 116.779, 123.68]:
             raise NotImplementedError("custom VGG_MEAN is not supported by the HIP preprocess kernel")
         bgr = K.vgg_preprocess(input_layer)          # x*255, RGB->BGR, - mean  (:149-153)
-        x, d1 = self.d1(bgr)
+        x, d1 = self.d1(K.vgg_preprocess(input_layer, 4))   # same, zero 4th channel: MFMA-friendly
         x, d2 = self.d2(x)
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)
@@ -121,5 +128,5 @@ class model(Layer):
         x = self.s2(self.u2(x, training), d2)
         x = self.s1(self.u1(x, training), d1)
         sc, sh = self.norm2.folded()
-        x = self.conv2(x, scale=sc, shift=sh, act2=K.ACT_RELU)     # (:183-185)
+        x = self.conv2.call_padded(x, cout_pad=16, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:183-185)
         return self.s0(x, bgr, act1=K.ACT_RELU)                    # relu(s0(x, bgr)) (:188-190)

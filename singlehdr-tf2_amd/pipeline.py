@@ -30,7 +30,8 @@ class Inference:
         A_pred = K.alpha_blend(B_pred, bgr_hal_res, self.threshold)
         out = A_pred
         if self._ref is not None:
-            out = self._ref(K.pack3([A_pred, B_pred, C_pred]), training=False)   # tf.concat([A,B,C],-1) (:108)
+            # tf.concat([A,B,C],-1) (:108), zero-padded to 12 channels for the MFMA tile
+            out = self._ref(K.pack3([A_pred, B_pred, C_pred], 12), training=False)
         if return_intermediates:
             return dict(C_pred=C_pred, invcrf=pred_invcrf, B_pred=B_pred, hal=bgr_hal_res, A_pred=A_pred,
                         hdr=out if self._ref is not None else None)

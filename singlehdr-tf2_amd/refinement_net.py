@@ -3,6 +3,9 @@
 refinement_net.py:31-66 of the reference: the Dequantization-Net U-Net with a
 9-channel input [A, B, C], bottleneck 128, no tanh; output
 relu(input[..., 0:3] + conv).  `training` is ignored (no BatchNorm).
+
+The input may also be given zero-padded to 12 channels ([A, B, C, 0]): the first
+7x7 conv then runs on the MFMA tile instead of the VALU fallback.
 """
 try:
     from . import _ops as K
@@ -19,4 +22,4 @@ class model(_unet):
     def call(self, input_images, training="training"):
         x = self._trunk(input_images)
         # relu(input[..., 0:3] + out(x))  (refinement_net.py:63-66): residual read with channel stride 9
-        return self.out(x, residual=input_images, act2=K.ACT_RELU)
+        return self.out.call_padded(x, cout_pad=16, residual=input_images, act2=K.ACT_RELU)

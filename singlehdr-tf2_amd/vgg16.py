@@ -37,6 +37,8 @@ class Vgg16(Layer):
             b = torch.as_tensor(np.asarray(data_dict[name][1]), dtype=torch.float32)
             if tuple(w.shape) != (3, 3, cin, cout) or tuple(b.shape) != (cout,):
                 raise ValueError("vgg16: %s has shape %s / %s" % (name, tuple(w.shape), tuple(b.shape)))
+            if cin == 3:   # zero-pad Cin 3 -> 4: the first conv runs on the MFMA tile
+                w = torch.cat([w, torch.zeros(3, 3, 1, cout)], dim=2)
             self.params[name] = (w.contiguous().to(device), b.contiguous().to(device))
 
     def _conv(self, name, x):
@@ -44,7 +46,7 @@ class Vgg16(Layer):
         return K.conv2d(x, w, b, act1=K.ACT_RELU)   # vgg16.py:33-35
 
     def call(self, rgb, training="training"):
-        x = K.vgg_preprocess(rgb)                    # vgg16.py:101-109
+        x = K.vgg_preprocess(rgb, 4)                 # vgg16.py:101-109 (+ zero 4th channel)
         x = self._conv("conv1_2", self._conv("conv1_1", x))
         pool1 = K.maxpool2(x)
         x = self._conv("conv2_2", self._conv("conv2_1", pool1))

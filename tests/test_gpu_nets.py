@@ -40,7 +40,10 @@ def test_dequantization_net_parity(shdr, hw):
 def test_refinement_net_parity(shdr):
     m, p = build(shdr, "ref", 22)
     x = np.random.default_rng(2).random((1, 64, 64, 9))
-    assert rel_err(host(m(dev(x), training=False)), nets.ref_forward(p, x)) <= TOL
+    ref = nets.ref_forward(p, x)
+    assert rel_err(host(m(dev(x), training=False)), ref) <= TOL                      # 9-channel input (reference surface)
+    x12 = np.concatenate([x, np.zeros((1, 64, 64, 3))], -1)
+    assert rel_err(host(m(dev(x12), training=False)), ref) <= TOL                    # zero-padded fast path
 
 
 def test_hallucination_net_parity(shdr):

@@ -61,6 +61,13 @@ CONV_CASES = [
     ("mfma_relu_bn_relu", 1, 16, 16, 128, 0, 64, 3, 1, dict(bias=True, act1=1, affine=True, act2=1)),
     ("mfma_small_8x8", 2, 8, 8, 128, 0, 128, 3, 1, dict(bias=True, act1=1)),
     ("mfma_tiny_4x4", 1, 4, 4, 256, 0, 256, 3, 1, dict(bias=True, act1=1)),
+    ("mfma_cin3pad4_7x7", 2, 16, 16, 3, 0, 16, 7, 1, dict(bias=True, act1=2, pad_cin=4)),
+    ("mfma_cin3pad4_3x3_to64", 1, 16, 16, 3, 0, 64, 3, 1, dict(bias=True, act1=1, pad_cin=4)),
+    ("mfma_cin9pad12_7x7", 1, 16, 16, 9, 0, 16, 7, 1, dict(bias=True, act1=2, pad_cin=12)),
+    ("mfma_cout3pad16_tanh_res", 1, 16, 16, 16, 0, 3, 3, 1, dict(bias=True, act1=3, residual=True, pad_cout=16)),
+    ("mfma_cout3pad16_res12_relu", 1, 16, 24, 16, 0, 3, 3, 1, dict(bias=True, residual=True, res_c=12, act2=1, pad_cout=16)),
+    ("mfma_cout3pad16_1x1_bn_relu", 2, 16, 16, 64, 0, 3, 1, 1, dict(bias=True, affine=True, act2=1, pad_cout=16)),
+    ("mfma_cout20pad32", 1, 8, 8, 32, 0, 20, 3, 1, dict(bias=True, act1=1, pad_cout=32)),
     ("direct_3to16_7x7", 2, 16, 16, 3, 0, 16, 7, 1, dict(bias=True, act1=2)),
     ("direct_3to64_3x3", 1, 16, 16, 3, 0, 64, 3, 1, dict(bias=True, act1=1)),
     ("direct_9to16_7x7", 1, 16, 16, 9, 0, 16, 7, 1, dict(bias=True, act1=2)),
@@ -86,11 +93,38 @@ def test_conv2d_parity(shdr, case):
     kw = dict(stride=stride, x2_scale=ex.get("x2_scale", 1.0), act1=ex.get("act1", 0), act2=ex.get("act2", 0))
     ref = oracle_conv(x, wt, bias, x2=x2, scale=scale, shift=shift, residual=res, **kw)
     K = shdr._ops
+    if "pad_cin" in ex:      # zero-padded input channels + zero filter taps: same result, MFMA tile
+        pc = ex["pad_cin"] - c1
+        x = np.concatenate([x, np.zeros((n, h, w, pc), np.float32)], -1)
+        wt = np.concatenate([wt, np.zeros((k, k, pc, cout), np.float32)], 2)
+    if "pad_cout" in ex:     # zero-padded filter columns, only `cout` channels stored
+        wt = np.concatenate([wt, np.zeros(wt.shape[:3] + (ex["pad_cout"] - cout,), np.float32)], 3)
+        kw["cout_valid"] = cout
+        kw["algo"] = K.ALGO_MFMA
+    if "pad_cin" in ex:
+        kw["algo"] = K.ALGO_MFMA
     y = K.conv2d(dev(x), dev(wt), None if bias is None else dev(bias), x2=None if x2 is None else dev(x2),
                  scale=None if scale is None else dev(scale), shift=None if shift is None else dev(shift),
                  residual=None if res is None else dev(res), **kw)
     assert tuple(y.shape) == ref.shape
     assert rel_err(host(y), ref) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 20, 64, 0, 128, 3, 1), (1, 16, 16, 32, 32, 64, 1, 1), (1, 20, 20, 16, 0, 32, 5, 1),
+                                   (1, 33, 17, 96, 0, 64, 7, 2), (1, 16, 16, 16, 16, 16, 3, 1), (2, 9, 9, 128, 0, 16, 3, 1),
+                                   (1, 16, 16, 12, 0, 16, 7, 1), (1, 8, 8, 4, 0, 64, 3, 1)])
+def test_conv2d_dma_and_register_kernels_bit_identical(shdr, shape):
+    """the LDS-DMA and the register-staged MFMA kernels run the same k-ordered fmaf chains"""
+    n, h, w, c1, c2, cout, k, stride = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x = dev(f32(rng.normal(size=(n, h, w, c1))))
+    x2 = dev(f32(rng.normal(size=(n, h, w, c2)))) if c2 else None
+    wt = dev(f32(rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2))))
+    b = dev(f32(rng.normal(size=cout)))
+    y_dma = K.conv2d(x, wt, b, stride=stride, x2=x2, act1=K.ACT_RELU, algo=K.ALGO_MFMA)
+    y_reg = K.conv2d(x, wt, b, stride=stride, x2=x2, act1=K.ACT_RELU, algo=K.ALGO_MFMA_REG)
+    assert rel_err(host(y_dma), host(y_reg)) <= 1e-6
 
 
 def test_conv2d_mfma_and_direct_agree(shdr):
@@ -222,6 +256,9 @@ def test_glue_ops_parity(shdr):
     np.testing.assert_array_equal(host(K.clip(dev(x), 0.0, 1.0)), np.clip(x, 0, 1))
     np.testing.assert_array_equal(host(K.reverse3(dev(x))), x[..., ::-1])
     np.testing.assert_allclose(host(K.vgg_preprocess(dev(x))), ops.vgg_preprocess(x.astype(np.float64)), rtol=1e-6, atol=1e-4)
+    v4 = host(K.vgg_preprocess(dev(x), 4))
+    np.testing.assert_array_equal(v4[..., :3], host(K.vgg_preprocess(dev(x))))
+    assert float(np.abs(v4[..., 3]).max()) == 0.0
     xp = np.abs(x)
     np.testing.assert_allclose(host(K.logc(dev(xp))), ops.log_compress(xp.astype(np.float64)), atol=1e-6)
     b = f32(rng.random((2, 6, 5, 3)))
