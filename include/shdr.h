@@ -90,6 +90,26 @@ int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
                         const float* bias, const float* scale, const float* shift,
                         const float* residual, float* y, void* stream);
 
+/*
+ * Convolution backward (GradientTape.gradient through Conv2D: joint_training.py:185,
+ * train.py:175,195,242, finetune_real_dataset.py:177).
+ *
+ * Weight gradient w.r.t. the rows of source `which` (0: x1, 1: x2) of the forward conv `d`:
+ *   dw[kh][kw][ci_off + ci][co] += scale * sum_{n,oh,ow} x[n, oh*s+kh-pad_t, ow*s+kw-pad_l, ci] * dz[n,oh,ow,co]
+ * (ci_off = 0 / C1, scale = 1 / x2_scale).  dz = gradient w.r.t. the pre-activation conv output,
+ * [N,Ho,Wo,cout_valid]; dw = the full [KH,KW,C1+C2,cout_valid] gradient, ACCUMULATED into (the
+ * caller zeroes it).  fp32 atomics: the summation order over pixel slices is not fixed.
+ */
+int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, int which, const float* dz,
+                          float* dw, void* stream);
+/* dgrad filter: wt[kh][kw][co][ci - c_begin] = scale * w[KH-1-kh][KW-1-kw][ci][co], ci in
+ * [c_begin, c_begin + c_count): the input gradient of a stride-1 SAME conv is
+ * shdr_conv2d_fwd_f32(dz, wt) with the same padding. */
+int shdr_filter_transform_f32(const float* w, float* wt, int KH, int KW, int Cin, int Cout,
+                              int c_begin, int c_count, float scale, void* stream);
+/* db[c] += sum_p dz[p][c] (bias gradient; the caller zeroes db). */
+int shdr_bias_grad_f32(const float* dz, float* db, int64_t npix, int C, void* stream);
+
 /* Spatial-aware soft histogram, parametric bin count
  * (linearization_net.py:336-350).  x [npix, C] -> y [npix, B*C], channel
  * order [bin1.c0..c(C-1), bin2...].  Bit-exact w.r.t. the IEEE fp32
@@ -147,6 +167,63 @@ int shdr_pack3_fwd_f32(const float* s0, const float* s1, const float* s2, const 
                        int nsrc, float* y, int out_channels, int64_t npix, void* stream);
 /* log(1+10x)/log(11) (joint_training.py:166,173). */
 int shdr_logc_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+
+/* ---- backward / training (GradientTape.gradient + Adam.apply_gradients:
+ *      joint_training.py:185-186, train.py:175-176,195-196,242-243,
+ *      finetune_real_dataset.py:177-178).  Parameter gradients (dw, db, dgamma,
+ *      dbeta, dwfc, dbfc, drf) are ACCUMULATED into buffers the caller zeroes. ---- */
+/* dx = dy * act'(.) evaluated from the activation OUTPUT y (relu / lrelu 0.1 / tanh). */
+int shdr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
+/* tf.clip_by_value gradient: passes where lo <= x <= hi. */
+int shdr_clip_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, float lo, float hi, void* stream);
+int shdr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* input gradients of the pooling / resize ops; N,H,W,C describe the op's INPUT x. */
+int shdr_avgpool2_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+int shdr_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+int shdr_maxpool3s2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+int shdr_gap_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream);
+/* dx[n,2i,2j,:] = dy[n,i,j,:], zero elsewhere (input gradient of a 1x1 stride-2 conv). */
+int shdr_upsample_zero2_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* BatchNormalization, training mode (linearization_net.py:13-25, hallucination_net.py:82,122,141):
+ * batch mean / biased variance over (N,H,W) accumulated in double (ws = 2*C doubles of caller
+ * workspace); optional Keras moving-average update (momentum 0.99, unbiased variance). */
+int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float* var, float* moving_mean,
+                      float* moving_var, int64_t npix, int C, float momentum, void* stream);
+int shdr_bn_train_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
+                            const float* beta, float* y, int64_t npix, int C, float eps, int relu,
+                            void* stream);
+/* y_relu != NULL: the forward applied relu after BN; dy is masked by y_relu > 0 first. */
+int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean,
+                    const float* var, const float* gamma, double* ws, float* dgamma, float* dbeta,
+                    float* dx, int64_t npix, int C, float eps, void* stream);
+int shdr_invcrf_decode_bwd_f32(const float* dinv, const float* feat, const float* wfc,
+                               const float* table, float* dfeat, float* dwfc, float* dbfc, int B,
+                               int F, int K, void* stream);
+int shdr_increase_bwd_f32(const float* rf, const float* dout, float* drf, int B, int K, void* stream);
+/* drf accumulated; dx may be NULL (joint training feeds data, not a prediction). */
+int shdr_apply_rf_bwd_f32(const float* x, const float* rf, const float* dy, float* drf, float* dx,
+                          int B, int64_t n_per_batch, int K, void* stream);
+/* per-sample mean loss out[b] = mean((a-b)^2) (mode 0, tf_utils.py:110-111) or mean|a-b| (mode 1,
+ * joint_training.py:169-173) and its gradient da = g[b] * d out[b] / d a. */
+int shdr_diff_loss_f32(const float* a, const float* b, float* out, int B, int64_t n_per_sample,
+                       int mode, void* stream);
+int shdr_diff_loss_bwd_f32(const float* a, const float* b, const float* g, float* da, int B,
+                           int64_t n_per_sample, int mode, int accumulate, void* stream);
+/* batch-global TV loss with SYMMETRIC pad (joint_training.py:175-179): out[0]. */
+int shdr_tv_loss_f32(const float* y, float* out, int N, int H, int W, int C, void* stream);
+int shdr_tv_loss_bwd_f32(const float* y, const float* g, float* dy, int N, int H, int W, int C,
+                         int accumulate, void* stream);
+int shdr_logc_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* alpha[p] = clamp((max_c x - 1 + thr)/thr, 0, 1) (joint_training.py:141-145). */
+int shdr_alpha_mask_f32(const float* x, float* alpha, int64_t npix, float thr, void* stream);
+/* d hal = reverse3(alpha * dA) for A = B + alpha * reverse3(hal), alpha constant. */
+int shdr_alpha_blend_bwd_f32(const float* dA, const float* alpha, float* dhal, int64_t npix, void* stream);
+int shdr_vgg_preprocess_bwd_f32(const float* dy, float* dx, int64_t npix, int in_channels, void* stream);
+/* Keras Adam on a flat buffer: g' = grad_scale*g; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ * p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int shdr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                  float beta2, float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ Put this directory on `sys.path` to use them under the reference's module
 names, or import them from this package.  All arithmetic runs in libshdr.so
 (hand-written HIP, C ABI in include/shdr.h); there is no CPU fallback.
 """
-from . import _lib, _ops, _layers  # noqa: F401
+from . import _lib, _ops, _autograd, _layers  # noqa: F401
 from . import dequantization_net, linearization_net, hallucination_net, refinement_net  # noqa: F401
 from . import vgg16, tf_utils, pipeline  # noqa: F401
 

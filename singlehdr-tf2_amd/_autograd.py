@@ -1,0 +1,318 @@
+"""Differentiable counterparts of the `_ops` wrappers.
+
+torch.autograd is used as the tape only (plumbing): every forward AND backward
+computation below is a libshdr HIP kernel.  `_ops.<op>` dispatches here when
+gradients are enabled and an input requires them; the fused inference
+epilogues (folded BatchNorm, residual, second activation) are not
+differentiable -- the training-mode network code does not use them.
+
+Replaces tf.GradientTape.gradient for the ops of the hot path
+(joint_training.py:147-185, train.py:165-242).
+"""
+import torch
+import torch.nn.functional as F
+
+try:
+    from . import _ops as K
+except ImportError:
+    import _ops as K
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------
+def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
+    """input gradient w.r.t. source channels [c_begin, c_begin+c_count) of the forward filter w"""
+    kh, kw = w.shape[0], w.shape[1]
+    cout_real = dz.shape[3]
+    if w.shape[3] != cout_real:                       # zero-padded filter columns carry no gradient
+        w = w[..., :cout_real].contiguous()
+    wt = K.filter_transform(w, c_begin, c_count, scale)
+    if stride == 1:
+        return K.conv2d(dz, wt)
+    if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
+        return K.upsample_zero2(K.conv2d(dz, wt), x_shape)
+    raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built "
+                              "(on the hot path only first layers are strided, and they take data)" % (kh, kw, stride))
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act1(conv(concat[x, x2_scale*x2], w) + bias)"""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, bias, stride, x2_scale, act1, cout_valid, algo):
+        y = K.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, algo=algo, cout_valid=cout_valid)
+        ctx.save_for_backward(x, x2, w, y)
+        ctx.meta = (stride, x2_scale, act1, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w, y = ctx.saved_tensors
+        stride, x2_scale, act1, has_bias = ctx.meta
+        dy = _c(dy)
+        dz = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
+        need_x, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
+        dx = dx2 = dw = db = None
+        c1 = x.shape[3]
+        if need_w:
+            kh, kw, cin, cout_gemm = w.shape
+            dw = K.conv2d_wgrad(x, x2, dz, (kh, kw, cin, dz.shape[3]), stride, x2_scale)
+            if dz.shape[3] != cout_gemm:
+                dw = F.pad(dw, (0, cout_gemm - dz.shape[3]))
+        if need_b and has_bias:
+            db = K.bias_grad(dz)
+        if need_x:
+            dx = _dgrad(dz, w, 0, c1, 1.0, stride, x.shape)
+        if need_x2 and x2 is not None:
+            dx2 = _dgrad(dz, w, c1, x2.shape[3], x2_scale, stride, x2.shape)
+        return dx, dx2, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=K.ACT_NONE, scale=None, shift=None,
+           residual=None, act2=K.ACT_NONE, algo=K.ALGO_AUTO, cout_valid=None):
+    if scale is not None or shift is not None or residual is not None or act2 != K.ACT_NONE:
+        raise NotImplementedError("the fused inference epilogue (folded BN / residual / act2) is not differentiable; "
+                                  "the training path applies these as separate ops")
+    return Conv2dFn.apply(x, x2, w, bias, stride, x2_scale, act1, cout_valid, algo)
+
+
+# ---------------------------------------------------------------------------
+# BatchNormalization, training mode
+# ---------------------------------------------------------------------------
+class BatchNormTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu):
+        x = _c(x)
+        mean, var = K.bn_stats(x, moving_mean, moving_var, momentum)
+        y = K.bn_train_apply(x, mean, var, gamma, beta, eps, relu)
+        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = K.bn_bwd(_c(dy), x, y, mean, var, gamma, ctx.eps)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, moving_mean, moving_var, eps, momentum, relu):
+    return BatchNormTrainFn.apply(x, gamma, beta, moving_mean, moving_var, eps, momentum, relu)
+
+
+# ---------------------------------------------------------------------------
+# pooling / resize / elementwise
+# ---------------------------------------------------------------------------
+def _simple(name, fwd, bwd):
+    """Function whose backward needs (saved tensors chosen by `fwd`, dy)"""
+    def forward(ctx, x, *args):
+        y, saved, meta = fwd(x, *args)
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
+        ctx.nargs = len(args)
+        return y
+
+    def backward(ctx, dy):
+        return (bwd(ctx.saved_tensors, ctx.meta, _c(dy)),) + (None,) * ctx.nargs
+
+    return type(name, (torch.autograd.Function,), {"forward": staticmethod(forward), "backward": staticmethod(backward)})
+
+
+AvgPool2Fn = _simple("AvgPool2Fn", lambda x: (K.avgpool2(x), (), tuple(x.shape)),
+                     lambda s, m, dy: K.avgpool2_bwd(dy, m))
+MaxPool2Fn = _simple("MaxPool2Fn", lambda x: (K.maxpool2(x), (x,), None),
+                     lambda s, m, dy: K.maxpool2_bwd(s[0], dy))
+MaxPool3s2Fn = _simple("MaxPool3s2Fn", lambda x: (K.maxpool3s2(x), (x,), None),
+                       lambda s, m, dy: K.maxpool3s2_bwd(s[0], dy))
+Resize2xFn = _simple("Resize2xFn", lambda x: (K.resize2x(x), (), tuple(x.shape)),
+                     lambda s, m, dy: K.resize2x_bwd(dy, m))
+GapFn = _simple("GapFn", lambda x: (K.global_avg_pool(x), (), tuple(x.shape)),
+                lambda s, m, dy: K.gap_bwd(dy, m))
+ClipFn = _simple("ClipFn", lambda x, lo, hi: (K.clip(x, lo, hi), (x,), (lo, hi)),
+                 lambda s, m, dy: K.clip_bwd(dy, s[0], m[0], m[1]))
+LogcFn = _simple("LogcFn", lambda x: (K.logc(x), (x,), None),
+                 lambda s, m, dy: K.logc_bwd(dy, s[0]))
+Reverse3Fn = _simple("Reverse3Fn", lambda x: (K.reverse3(x), (), None),
+                     lambda s, m, dy: K.reverse3(dy))
+VggPreFn = _simple("VggPreFn", lambda x, oc: (K.vgg_preprocess(x, oc), (), None),
+                   lambda s, m, dy: K.vgg_preprocess_bwd(dy))
+IncreaseFn = _simple("IncreaseFn", lambda rf: (K.increase(rf), (rf,), None),
+                     lambda s, m, dy: K.increase_bwd(s[0], dy))
+
+
+def avgpool2(x):
+    return AvgPool2Fn.apply(x)
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+def maxpool3s2(x):
+    return MaxPool3s2Fn.apply(x)
+
+
+def resize2x(x):
+    return Resize2xFn.apply(x)
+
+
+def global_avg_pool(x):
+    return GapFn.apply(x)
+
+
+def clip(x, lo, hi):
+    return ClipFn.apply(x, lo, hi)
+
+
+def logc(x):
+    return LogcFn.apply(x)
+
+
+def reverse3(x):
+    return Reverse3Fn.apply(x)
+
+
+def vgg_preprocess(x, out_channels=3):
+    return VggPreFn.apply(x, out_channels)
+
+
+def increase(rf):
+    return IncreaseFn.apply(rf)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class AddReluFn(torch.autograd.Function):
+    """relu(a + b) -- the residual join of the Linearization-Net blocks in training mode"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        y = K.clip(K.add(a, b), 0.0, float("inf"))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        d = K.act_bwd(_c(dy), y, K.ACT_RELU)
+        return d, d
+
+
+def add_relu(a, b):
+    return AddReluFn.apply(a, b)
+
+
+# ---------------------------------------------------------------------------
+# inverse-CRF head, CRF application
+# ---------------------------------------------------------------------------
+class InvcrfDecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, wfc, bfc, table):
+        ctx.save_for_backward(feat, wfc, table)
+        return K.invcrf_decode(feat, wfc, bfc, table)
+
+    @staticmethod
+    def backward(ctx, dinv):
+        feat, wfc, table = ctx.saved_tensors
+        dfeat, dwfc, dbfc = K.invcrf_decode_bwd(_c(dinv), feat, wfc, table)
+        return dfeat, dwfc, dbfc, None
+
+
+def invcrf_decode(feat, wfc, bfc, table):
+    return InvcrfDecodeFn.apply(feat, wfc, bfc, table)
+
+
+class ApplyRfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rf):
+        ctx.save_for_backward(x, rf)
+        return K.apply_rf(x, rf)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rf = ctx.saved_tensors
+        drf, dx = K.apply_rf_bwd(x, rf, _c(dy), ctx.needs_input_grad[0])
+        return dx, (drf if ctx.needs_input_grad[1] else None)
+
+
+def apply_rf(x, rf):
+    return ApplyRfFn.apply(x, rf)
+
+
+# ---------------------------------------------------------------------------
+# losses and the blend of the joint step
+# ---------------------------------------------------------------------------
+class DiffLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        ctx.save_for_backward(a, b)
+        ctx.mode = mode
+        return K.diff_loss(a, b, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        da = K.diff_loss_bwd(a, b, g, ctx.mode) if ctx.needs_input_grad[0] else None
+        db = K.diff_loss_bwd(b, a, g, ctx.mode) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+def diff_loss(a, b, mode):
+    return DiffLossFn.apply(a, b, mode)
+
+
+class TvLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return K.tv_loss(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return K.tv_loss_bwd(y, _c(g))
+
+
+def tv_loss(y):
+    return TvLossFn.apply(y)
+
+
+class BlendConstFn(torch.autograd.Function):
+    """A = base + alpha * reverse3(hal); base, alpha are data (joint_training.py:163-165)"""
+
+    @staticmethod
+    def forward(ctx, base, alpha, hal_bgr, thr):
+        ctx.save_for_backward(alpha)
+        return K.alpha_blend(base, hal_bgr, thr)   # recomputes the same alpha from `base`
+
+    @staticmethod
+    def backward(ctx, dA):
+        (alpha,) = ctx.saved_tensors
+        return None, None, K.alpha_blend_bwd(_c(dA), alpha), None
+
+
+def blend_const(base, alpha, hal_bgr, thr):
+    return BlendConstFn.apply(base, alpha, hal_bgr, thr)
+
+
+import sys  # noqa: E402
+
+K.AUTOGRAD = sys.modules[__name__]

@@ -10,6 +10,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 try:
     from . import _ops as K
@@ -133,8 +134,14 @@ class Conv2D(Layer):
 
     def call_padded(self, x, cin_pad=None, cout_pad=None, **kw):
         """Run on the MFMA tile with a zero-padded filter; stores only the true output channels."""
-        return K.conv2d(x, self.kernel_padded(cin_pad, cout_pad), self.bias, stride=self.strides,
-                        cout_valid=self.kernel.shape[3], **kw)
+        if torch.is_grad_enabled() and self.kernel.requires_grad:
+            # training: the padding is part of the tape (F.pad is parameter-sized plumbing), so the
+            # gradient of the padded filter is sliced back onto the variable
+            k = self.kernel
+            w = F.pad(k, (0, (cout_pad or k.shape[3]) - k.shape[3], 0, (cin_pad or k.shape[2]) - k.shape[2]))
+        else:
+            w = self.kernel_padded(cin_pad, cout_pad)
+        return K.conv2d(x, w, self.bias, stride=self.strides, cout_valid=self.kernel.shape[3], **kw)
 
     def call(self, x, **kw):
         return K.conv2d(x, self.kernel, self.bias, stride=self.strides, **kw)
@@ -163,6 +170,12 @@ class BatchNormalization(Layer):
             self._folded = (ver, scale.contiguous(), shift.contiguous())
         return self._folded[1], self._folded[2]
 
+    def train_apply(self, x, relu=False):
+        """Training mode: normalise with the batch statistics (biased variance), update the moving
+        statistics in place (momentum 0.99, unbiased variance), optional fused relu."""
+        return K.AUTOGRAD.batch_norm_train(x, self.gamma, self.beta, self.moving_mean, self.moving_variance,
+                                           BN_EPS, BN_MOMENTUM, relu)
+
 
 class Dense(Layer):
     """tf.keras.layers.Dense(units)."""
@@ -177,3 +190,8 @@ class Dense(Layer):
 def is_training(training):
     """The reference passes `training="training"` (a truthy string) by default."""
     return bool(training)
+
+
+def taping(*tensors):
+    """True when the call is being recorded for backward (gradients enabled and some input needs them)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -34,6 +34,9 @@ SIGNATURES = {
     "shdr_version": (ctypes.c_char_p, []),
     "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_conv2d_wgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
+    "shdr_filter_transform_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr]),
+    "shdr_bias_grad_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "shdr_soft_hist_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_lin_frontend_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_avgpool2_fwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
@@ -50,6 +53,30 @@ SIGNATURES = {
     "shdr_alpha_blend_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     "shdr_pack3_fwd_f32": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_ptr]),
     "shdr_logc_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_act_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_clip_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_ptr]),
+    "shdr_add_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_avgpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_resize2x_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_gap_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "shdr_upsample_zero2_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_bn_stats_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_ptr]),
+    "shdr_bn_train_apply_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr]),
+    "shdr_bn_bwd_f32": (c_int, [c_ptr] * 10 + [c_i64, c_int, c_f32, c_ptr]),
+    "shdr_invcrf_decode_bwd_f32": (c_int, [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr]),
+    "shdr_increase_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    "shdr_apply_rf_bwd_f32": (c_int, [c_ptr] * 5 + [c_int, c_i64, c_int, c_ptr]),
+    "shdr_diff_loss_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr]),
+    "shdr_diff_loss_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr]),
+    "shdr_tv_loss_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_tv_loss_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_logc_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_alpha_mask_f32": (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
+    "shdr_alpha_blend_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_vgg_preprocess_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_adam_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
 }
 
 _lib = None

@@ -14,6 +14,14 @@ try:
 except ImportError:  # package directory itself on sys.path (drop-in module layout)
     import _lib
 
+AUTOGRAD = None   # set by _autograd on import: module with the differentiable counterparts
+
+
+def _needs_grad(*tensors):
+    return AUTOGRAD is not None and torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 
@@ -57,6 +65,10 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
 
     `cout_valid` < w.shape[3] says the filter is zero-padded along Cout (to a multiple of 16 so
     that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored."""
+    fused = scale is not None or shift is not None or residual is not None or act2 != ACT_NONE
+    if not fused and _needs_grad(x, x2, w, bias):     # fused epilogues are the inference path: never taped
+        return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
+                               shift=shift, residual=residual, act2=act2, algo=algo, cout_valid=cout_valid)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     w = _chk(_d(w), "w")
@@ -116,26 +128,36 @@ def _nhwc_op(fn_name, x, out_shape):
 
 
 def avgpool2(x):
+    if _needs_grad(x):
+        return AUTOGRAD.avgpool2(x)
     n, h, w, c = x.shape
     return _nhwc_op("shdr_avgpool2_fwd_f32", x, (n, h // 2, w // 2, c))
 
 
 def maxpool2(x):
+    if _needs_grad(x):
+        return AUTOGRAD.maxpool2(x)
     n, h, w, c = x.shape
     return _nhwc_op("shdr_maxpool2_fwd_f32", x, (n, h // 2, w // 2, c))
 
 
 def maxpool3s2(x):
+    if _needs_grad(x):
+        return AUTOGRAD.maxpool3s2(x)
     n, h, w, c = x.shape
     return _nhwc_op("shdr_maxpool3s2_fwd_f32", x, (n, same_pad(h, 3, 2)[0], same_pad(w, 3, 2)[0], c))
 
 
 def resize2x(x):
+    if _needs_grad(x):
+        return AUTOGRAD.resize2x(x)
     n, h, w, c = x.shape
     return _nhwc_op("shdr_resize2x_fwd_f32", x, (n, 2 * h, 2 * w, c))
 
 
 def global_avg_pool(x):
+    if _needs_grad(x):
+        return AUTOGRAD.global_avg_pool(x)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     n, h, w, c = x.shape
@@ -169,6 +191,8 @@ def lin_frontend(img, channels=96):
 
 
 def invcrf_decode(feat, wfc, bfc, table):
+    if _needs_grad(feat, wfc, bfc):
+        return AUTOGRAD.invcrf_decode(feat, wfc, bfc, table)
     lib = _lib.load()
     feat, wfc, bfc, table = (_chk(_d(t), nm) for t, nm in
                              ((feat, "feat"), (wfc, "wfc"), (bfc, "bfc"), (table, "table")))
@@ -183,6 +207,8 @@ def invcrf_decode(feat, wfc, bfc, table):
 
 
 def increase(rf):
+    if _needs_grad(rf):
+        return AUTOGRAD.increase(rf)
     lib = _lib.load()
     rf = _chk(_d(rf), "rf")
     b, k = rf.shape
@@ -192,6 +218,8 @@ def increase(rf):
 
 
 def apply_rf(x, rf):
+    if _needs_grad(x, rf):
+        return AUTOGRAD.apply_rf(x, rf)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     rf = _chk(_d(rf), "rf")
@@ -205,6 +233,8 @@ def apply_rf(x, rf):
 
 
 def clip(x, lo, hi):
+    if _needs_grad(x):
+        return AUTOGRAD.clip(x, lo, hi)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     y = torch.empty_like(x)
@@ -214,6 +244,8 @@ def clip(x, lo, hi):
 
 
 def logc(x):
+    if _needs_grad(x):
+        return AUTOGRAD.logc(x)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     y = torch.empty_like(x)
@@ -230,6 +262,8 @@ def _pix3(x, name):
 
 def vgg_preprocess(x, out_channels=3):
     """x*255, RGB->BGR, minus VGG mean; out_channels=4 appends a zero channel (MFMA-friendly)."""
+    if _needs_grad(x):
+        return AUTOGRAD.vgg_preprocess(x, out_channels)
     lib = _lib.load()
     x, npix = _pix3(x, "x")
     y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=torch.float32)
@@ -239,6 +273,8 @@ def vgg_preprocess(x, out_channels=3):
 
 
 def reverse3(x):
+    if _needs_grad(x):
+        return AUTOGRAD.reverse3(x)
     lib = _lib.load()
     x, npix = _pix3(x, "x")
     y = torch.empty_like(x)
@@ -247,6 +283,8 @@ def reverse3(x):
 
 
 def alpha_blend(b_pred, hal_bgr, thr=0.12, return_alpha=False):
+    if _needs_grad(b_pred, hal_bgr):
+        raise NotImplementedError("alpha_blend: use alpha_mask() + blend_const() on the training path")
     lib = _lib.load()
     b_pred, npix = _pix3(b_pred, "b_pred")
     hal_bgr, npix2 = _pix3(hal_bgr, "hal_bgr")
@@ -273,3 +311,297 @@ def pack3(srcs, out_channels=None):
     _lib.check(lib.shdr_pack3_fwd_f32(p[0], p[1], p[2], p[3], n, _ptr(y), oc, srcs[0].numel() // 3,
                                       _stream()), "shdr_pack3_fwd_f32")
     return y
+
+
+# ---------------------------------------------------------------------------
+# raw wrappers of the backward / training kernels (no autograd; see _autograd.py)
+# ---------------------------------------------------------------------------
+def _conv_desc(x_shape, w_shape, stride, c2, x2_scale, cout_valid):
+    n, h, wd, c1 = x_shape
+    kh, kw, cin, cout_gemm = w_shape
+    ho, pt = same_pad(h, kh, stride)
+    wo, pl = same_pad(wd, kw, stride)
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
+    d.Cout, d.KH, d.KW, d.stride = cout_gemm, kh, kw, stride
+    d.cout_valid = cout_valid or cout_gemm
+    d.pad_t, d.pad_l, d.Ho, d.Wo = pt, pl, ho, wo
+    d.x2_scale = float(x2_scale)
+    return d
+
+
+def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
+    """dW [kh,kw,C1+C2,Cout] of conv(concat[x, x2_scale*x2], W) given dz = dL/d(conv output)."""
+    lib = _lib.load()
+    x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
+    c2 = 0 if x2 is None else _chk(_d(x2), "x2").shape[3]
+    kh, kw, cin, cout = w_shape
+    if cin != x.shape[3] + c2 or cout != dz.shape[3]:
+        raise ValueError("conv2d_wgrad: filter %s does not match x %s (+%d) / dz %s"
+                         % (tuple(w_shape), tuple(x.shape), c2, tuple(dz.shape)))
+    d = _conv_desc(x.shape, w_shape, stride, c2, x2_scale, None)
+    if tuple(dz.shape[:3]) != (x.shape[0], d.Ho, d.Wo):
+        raise ValueError("conv2d_wgrad: dz spatial shape mismatch")
+    dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_conv2d_wgrad_f32(ctypes.byref(d), _ptr(x), 0, _ptr(dz), _ptr(dw), _stream()), "shdr_conv2d_wgrad_f32")
+    if x2 is not None:
+        _lib.check(lib.shdr_conv2d_wgrad_f32(ctypes.byref(d), _ptr(_d(x2)), 1, _ptr(dz), _ptr(dw), _stream()),
+                   "shdr_conv2d_wgrad_f32")
+    return dw
+
+
+def filter_transform(w, c_begin, c_count, scale=1.0):
+    """wt[kh,kw,co,ci] = scale * w[KH-1-kh, KW-1-kw, c_begin+ci, co]: the dgrad filter."""
+    lib = _lib.load()
+    w = _chk(_d(w), "w")
+    kh, kw, cin, cout = w.shape
+    wt = torch.empty((kh, kw, cout, c_count), device=w.device, dtype=torch.float32)
+    _lib.check(lib.shdr_filter_transform_f32(_ptr(w), _ptr(wt), kh, kw, cin, cout, c_begin, c_count, float(scale), _stream()),
+               "shdr_filter_transform_f32")
+    return wt
+
+
+def bias_grad(dz):
+    lib = _lib.load()
+    dz = _chk(_d(dz), "dz")
+    c = dz.shape[-1]
+    db = torch.zeros(c, device=dz.device, dtype=torch.float32)
+    _lib.check(lib.shdr_bias_grad_f32(_ptr(dz), _ptr(db), dz.numel() // c, c, _stream()), "shdr_bias_grad_f32")
+    return db
+
+
+def act_bwd(dy, y, act):
+    lib = _lib.load()
+    dy, y = _chk(_d(dy), "dy"), _chk(_d(y), "y")
+    dx = torch.empty_like(dy)
+    _lib.check(lib.shdr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), act, _stream()), "shdr_act_bwd_f32")
+    return dx
+
+
+def clip_bwd(dy, x, lo, hi):
+    lib = _lib.load()
+    dy, x = _chk(_d(dy), "dy"), _chk(_d(x), "x")
+    dx = torch.empty_like(dy)
+    _lib.check(lib.shdr_clip_bwd_f32(_ptr(dy), _ptr(x), _ptr(dx), dy.numel(), float(lo), float(hi), _stream()), "shdr_clip_bwd_f32")
+    return dx
+
+
+def add(a, b):
+    if _needs_grad(a, b):
+        return AUTOGRAD.add(a, b)
+    lib = _lib.load()
+    a, b = _chk(_d(a), "a"), _chk(_d(b), "b")
+    if a.shape != b.shape:
+        raise ValueError("add: shape mismatch")
+    y = torch.empty_like(a)
+    _lib.check(lib.shdr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "shdr_add_f32")
+    return y
+
+
+def _bwd_nhwc(fn_name, x_shape, *tensors):
+    """input-gradient kernels taking (tensors..., dx, N, H, W, C) of the op's INPUT shape"""
+    lib = _lib.load()
+    ts = [_chk(_d(t), "t%d" % i) for i, t in enumerate(tensors)]
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), device=ts[0].device, dtype=torch.float32)
+    _lib.check(getattr(lib, fn_name)(*[_ptr(t) for t in ts], _ptr(dx), n, h, w, c, _stream()), fn_name)
+    return dx
+
+
+def avgpool2_bwd(dy, x_shape):
+    return _bwd_nhwc("shdr_avgpool2_bwd_f32", x_shape, dy)
+
+
+def maxpool2_bwd(x, dy):
+    return _bwd_nhwc("shdr_maxpool2_bwd_f32", x.shape, x, dy)
+
+
+def maxpool3s2_bwd(x, dy):
+    return _bwd_nhwc("shdr_maxpool3s2_bwd_f32", x.shape, x, dy)
+
+
+def resize2x_bwd(dy, x_shape):
+    return _bwd_nhwc("shdr_resize2x_bwd_f32", x_shape, dy)
+
+
+def upsample_zero2(dy, x_shape):
+    return _bwd_nhwc("shdr_upsample_zero2_f32", x_shape, dy)
+
+
+def gap_bwd(dy, x_shape):
+    lib = _lib.load()
+    dy = _chk(_d(dy), "dy")
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    _lib.check(lib.shdr_gap_bwd_f32(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), "shdr_gap_bwd_f32")
+    return dx
+
+
+def _bn_ws(c, device):
+    return torch.empty(2 * c, device=device, dtype=torch.float64)
+
+
+def bn_stats(x, moving_mean=None, moving_var=None, momentum=0.99):
+    """batch mean / biased variance over (N,H,W); optionally updates the moving statistics in place."""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    c = x.shape[-1]
+    mean = torch.empty(c, device=x.device, dtype=torch.float32)
+    var = torch.empty(c, device=x.device, dtype=torch.float32)
+    ws = _bn_ws(c, x.device)
+    _lib.check(lib.shdr_bn_stats_f32(_ptr(x), _ptr(ws), _ptr(mean), _ptr(var), _ptr(_d(moving_mean)), _ptr(_d(moving_var)),
+                                     x.numel() // c, c, float(momentum), _stream()), "shdr_bn_stats_f32")
+    return mean, var
+
+
+def bn_train_apply(x, mean, var, gamma, beta, eps, relu):
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(lib.shdr_bn_train_apply_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
+                                           x.numel() // c, c, float(eps), int(bool(relu)), _stream()), "shdr_bn_train_apply_f32")
+    return y
+
+
+def bn_bwd(dy, x, y_relu, mean, var, gamma, eps):
+    lib = _lib.load()
+    dy, x = _chk(_d(dy), "dy"), _chk(_d(x), "x")
+    c = x.shape[-1]
+    dgamma = torch.zeros(c, device=x.device, dtype=torch.float32)
+    dbeta = torch.zeros(c, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    ws = _bn_ws(c, x.device)
+    _lib.check(lib.shdr_bn_bwd_f32(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
+                                   _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _stream()), "shdr_bn_bwd_f32")
+    return dx, dgamma, dbeta
+
+
+def invcrf_decode_bwd(dinv, feat, wfc, table):
+    lib = _lib.load()
+    dinv, feat, wfc, table = (_chk(_d(t), "t") for t in (dinv, feat, wfc, table))
+    b, f = feat.shape
+    k = table.shape[0]
+    dfeat = torch.empty_like(feat)
+    dwfc = torch.zeros_like(wfc)
+    dbfc = torch.zeros(11, device=feat.device, dtype=torch.float32)
+    _lib.check(lib.shdr_invcrf_decode_bwd_f32(_ptr(dinv), _ptr(feat), _ptr(wfc), _ptr(table), _ptr(dfeat), _ptr(dwfc),
+                                              _ptr(dbfc), b, f, k, _stream()), "shdr_invcrf_decode_bwd_f32")
+    return dfeat, dwfc, dbfc
+
+
+def increase_bwd(rf, dout):
+    lib = _lib.load()
+    rf, dout = _chk(_d(rf), "rf"), _chk(_d(dout), "dout")
+    b, k = rf.shape
+    drf = torch.empty_like(rf)
+    _lib.check(lib.shdr_increase_bwd_f32(_ptr(rf), _ptr(dout), _ptr(drf), b, k, _stream()), "shdr_increase_bwd_f32")
+    return drf
+
+
+def apply_rf_bwd(x, rf, dy, need_dx):
+    lib = _lib.load()
+    x, rf, dy = _chk(_d(x), "x"), _chk(_d(rf), "rf"), _chk(_d(dy), "dy")
+    b = x.shape[0]
+    drf = torch.zeros_like(rf)
+    dx = torch.empty_like(x) if need_dx else None
+    _lib.check(lib.shdr_apply_rf_bwd_f32(_ptr(x), _ptr(rf), _ptr(dy), _ptr(drf), _ptr(dx), b, x.numel() // b, rf.shape[1],
+                                         _stream()), "shdr_apply_rf_bwd_f32")
+    return drf, dx
+
+
+def diff_loss(a, b, mode):
+    """per-sample mean of (a-b)^2 (mode 0) or |a-b| (mode 1): [B]"""
+    if _needs_grad(a, b):
+        return AUTOGRAD.diff_loss(a, b, mode)
+    lib = _lib.load()
+    a, b = _chk(_d(a), "a"), _chk(_d(b), "b")
+    if a.shape != b.shape:
+        raise ValueError("diff_loss: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    bs = a.shape[0]
+    out = torch.empty(bs, device=a.device, dtype=torch.float32)
+    _lib.check(lib.shdr_diff_loss_f32(_ptr(a), _ptr(b), _ptr(out), bs, a.numel() // bs, mode, _stream()), "shdr_diff_loss_f32")
+    return out
+
+
+def diff_loss_bwd(a, b, g, mode):
+    lib = _lib.load()
+    a, b, g = _chk(_d(a), "a"), _chk(_d(b), "b"), _chk(_d(g), "g")
+    bs = a.shape[0]
+    da = torch.empty_like(a)
+    _lib.check(lib.shdr_diff_loss_bwd_f32(_ptr(a), _ptr(b), _ptr(g), _ptr(da), bs, a.numel() // bs, mode, 0, _stream()),
+               "shdr_diff_loss_bwd_f32")
+    return da
+
+
+def tv_loss(y):
+    """batch-global TV loss (joint_training.py:175-179): tensor [1]"""
+    if _needs_grad(y):
+        return AUTOGRAD.tv_loss(y)
+    lib = _lib.load()
+    y = _chk(_d(y), "y")
+    n, h, w, c = y.shape
+    out = torch.empty(1, device=y.device, dtype=torch.float32)
+    _lib.check(lib.shdr_tv_loss_f32(_ptr(y), _ptr(out), n, h, w, c, _stream()), "shdr_tv_loss_f32")
+    return out
+
+
+def tv_loss_bwd(y, g):
+    lib = _lib.load()
+    y, g = _chk(_d(y), "y"), _chk(_d(g), "g")
+    n, h, w, c = y.shape
+    dy = torch.empty_like(y)
+    _lib.check(lib.shdr_tv_loss_bwd_f32(_ptr(y), _ptr(g), _ptr(dy), n, h, w, c, 0, _stream()), "shdr_tv_loss_bwd_f32")
+    return dy
+
+
+def logc_bwd(dy, x):
+    lib = _lib.load()
+    dy, x = _chk(_d(dy), "dy"), _chk(_d(x), "x")
+    dx = torch.empty_like(x)
+    _lib.check(lib.shdr_logc_bwd_f32(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), _stream()), "shdr_logc_bwd_f32")
+    return dx
+
+
+def alpha_mask(x, thr=0.12):
+    """alpha [b,h,w,1] = clamp((max_c x - 1 + thr)/thr, 0, 1) (joint_training.py:141-145); no gradient."""
+    lib = _lib.load()
+    x, npix = _pix3(x, "x")
+    alpha = torch.empty(tuple(x.shape[:-1]) + (1,), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_alpha_mask_f32(_ptr(x), _ptr(alpha), npix, float(thr), _stream()), "shdr_alpha_mask_f32")
+    return alpha
+
+
+def alpha_blend_bwd(dA, alpha):
+    lib = _lib.load()
+    dA, npix = _pix3(dA, "dA")
+    alpha = _chk(_d(alpha), "alpha")
+    dhal = torch.empty_like(dA)
+    _lib.check(lib.shdr_alpha_blend_bwd_f32(_ptr(dA), _ptr(alpha), _ptr(dhal), npix, _stream()), "shdr_alpha_blend_bwd_f32")
+    return dhal
+
+
+def blend_const(base, alpha, hal_bgr, thr=0.12):
+    """A = base + alpha * reverse3(hal) with base and alpha constants (joint_training.py:163-165)."""
+    if _needs_grad(hal_bgr):
+        return AUTOGRAD.blend_const(base, alpha, hal_bgr, thr)
+    return alpha_blend(base, hal_bgr, thr)
+
+
+def vgg_preprocess_bwd(dy):
+    lib = _lib.load()
+    dy = _chk(_d(dy), "dy")
+    ic = dy.shape[-1]
+    npix = dy.numel() // ic
+    dx = torch.empty(tuple(dy.shape[:-1]) + (3,), device=dy.device, dtype=torch.float32)
+    _lib.check(lib.shdr_vgg_preprocess_bwd_f32(_ptr(dy), _ptr(dx), npix, ic, _stream()), "shdr_vgg_preprocess_bwd_f32")
+    return dx
+
+
+def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """in-place Keras Adam update of the flat parameter buffer `p`"""
+    lib = _lib.load()
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(_d(t), nm)
+    _lib.check(lib.shdr_adam_f32(_ptr(_d(p)), _ptr(_d(g)), _ptr(m), _ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+                                 float(eps), float(grad_scale), _stream()), "shdr_adam_f32")

@@ -20,6 +20,8 @@ LIB = os.path.join(HERE, "libshdr.so")
 SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
+    "wgrad.hip": [],
+    "bwd.hip": [],
     "frontend.hip": ["-ffp-contract=off"],
     "pool.hip": [],
     "crf.hip": [],

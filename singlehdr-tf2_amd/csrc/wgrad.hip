@@ -1,0 +1,357 @@
+// Convolution backward on gfx950: weight gradient and the filter transform used by dgrad.
+//
+//   dW[kh][kw][ci][co] += x_scale * sum_{n,oh,ow} X[n, oh*s+kh-pt, ow*s+kw-pl, ci] * dZ[n,oh,ow,co]
+//
+//  * wgrad_mfma_kernel: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) with the contraction over
+//    PIXELS: D[ci][co] = sum_p Xs[p][ci] * dZ[p][co].  Both operands are pixel-major /
+//    channel-contiguous in HBM, so a chunk of 32 pixels x (BMc | BNc) channels goes to LDS by
+//    global_load_lds_dwordx4 (lane-linear image, column swizzle c ^ 16*(p&1) applied on the source
+//    side, zero page for taps that fall into the padding).  One block = one filter tap x one
+//    (ci, co) tile x one slice of pixels; partial tiles are accumulated into dW with fp32 atomics
+//    (each wave instruction adds 4 rows x 64 contiguous bytes).
+//  * wgrad_direct_kernel: VALU fallback for channel counts the MFMA tile cannot take.
+//  * dgrad itself is the forward kernel run on dZ with the transformed filter
+//    Wt[kh][kw][co][ci] = W[KH-1-kh][KW-1-kw][ci][co]  (filter_transform_kernel).
+//
+// Replaces GradientTape.gradient through tf.keras.layers.Conv2D (joint_training.py:185,
+// train.py:175,195,242, finetune_real_dataset.py:177).
+#include <type_traits>
+
+#include "shdr_internal.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __attribute__((aligned(16))) float g_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct WgradArgs {
+  const float* x;    // [N,H,W,Cx]
+  const float* dz;   // [N,Ho,Wo,Cout]
+  float* dw;         // [KH*KW][Ct][Cout]
+  int N, H, W, Cx, Ct, ci_off, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+  int npix;          // N*Ho*Wo
+  int slice;         // pixels per block (multiple of 32)
+  int nslices;
+  int tiles_m, tiles_n;
+  float x_scale;
+};
+
+constexpr int PK = 32;  // pixels per chunk
+
+template <int BMc, int BNc, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
+  static_assert(WM * WN <= 4, "at most 4 computing waves (the others only feed the DMA)");
+  constexpr int MT = BMc / WM / 16;   // 16-ci groups per computing wave
+  constexpr int NT = BNc / WN / 16;
+  static_assert(MT >= 1 && NT >= 1 && MT * WM * 16 == BMc && NT * WN * 16 == BNc, "wave tiles must cover the block tile");
+  constexpr int XQ = BMc / 4, ZQ = BNc / 4;          // quads per pixel row
+  constexpr int XI_TOTAL = PK * XQ / 64, ZI_TOTAL = PK * ZQ / 64;   // wave DMA instructions per chunk
+  constexpr int XI = (XI_TOTAL + 3) / 4, ZI = (ZI_TOTAL + 3) / 4;   // per wave
+  constexpr int X_WAVES = XI_TOTAL >= 4 ? 4 : XI_TOTAL, Z_WAVES = ZI_TOTAL >= 4 ? 4 : ZI_TOTAL;
+  constexpr bool XSWZ = BMc >= 32, ZSWZ = BNc >= 32;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                       // [2][PK][BMc]
+  float* Zs = smem + 2 * PK * BMc;        // [2][PK][BNc]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool computing = wave < WM * WN;
+  const int wm = (wave / WN) % WM, wn = wave % WN;
+  int t = blockIdx.x;
+  const int tn = t % a.tiles_n; t /= a.tiles_n;
+  const int tm = t % a.tiles_m; t /= a.tiles_m;
+  const int tap = t;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int ci0 = tm * BMc, co0 = tn * BNc;
+  const int p_begin = blockIdx.y * a.slice;
+  const int p_end = min(p_begin + a.slice, a.npix);
+  const int nchunks = (p_end - p_begin + PK - 1) / PK;
+  const float* zero = g_wg_zero_page;
+
+  // lane -> (pixel in chunk, channel quad) of each DMA instruction
+  int xp[XI], xc[XI], zp[ZI], zc[ZI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int Q = (wave * XI + i) * 64 + lane;
+    xp[i] = Q / XQ;
+    const int pq = Q % XQ;
+    xc[i] = 4 * (XSWZ ? (pq ^ (4 * (xp[i] & 1))) : pq);
+  }
+#pragma unroll
+  for (int i = 0; i < ZI; ++i) {
+    const int Q = (wave * ZI + i) * 64 + lane;
+    zp[i] = Q / ZQ;
+    const int pq = Q % ZQ;
+    zc[i] = 4 * (ZSWZ ? (pq ^ (4 * (zp[i] & 1))) : pq);
+  }
+
+  // (n, oh, ow) of this lane's pixel for each X instruction, advanced by PK pixels per chunk
+  int s_ow[XI], s_oh[XI], s_n[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int p = p_begin + xp[i];
+    s_ow[i] = p % a.Wo;
+    const int q = p / a.Wo;
+    s_oh[i] = q % a.Ho;
+    s_n[i] = q / a.Ho;
+  }
+
+  auto dma_chunk = [&](int c, int buf) {
+    const int p0 = p_begin + c * PK;
+    float* Xb = Xs + buf * PK * BMc + (wave * XI) * 256;
+    float* Zb = Zs + buf * PK * BNc + (wave * ZI) * 256;
+    if (wave < X_WAVES) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int p = p0 + xp[i];
+        const int ih = s_oh[i] * a.stride - a.pad_t + kh, iw = s_ow[i] * a.stride - a.pad_l + kw;
+        const bool ok = p < p_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        const float* src = ok ? a.x + ((size_t)((s_n[i] * a.H + ih) * a.W + iw) * a.Cx + ci0 + xc[i]) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xb + i * 256), 16, 0, 0);
+        s_ow[i] += PK;
+        while (s_ow[i] >= a.Wo) {
+          s_ow[i] -= a.Wo;
+          if (++s_oh[i] == a.Ho) { s_oh[i] = 0; ++s_n[i]; }
+        }
+      }
+    }
+    if (wave < Z_WAVES) {
+#pragma unroll
+      for (int i = 0; i < ZI; ++i) {
+        const int p = p0 + zp[i];
+        const float* src = p < p_end ? a.dz + ((size_t)p * a.Cout + co0 + zc[i]) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Zb + i * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fg = lane >> 4;
+  int xcol[MT], zcol[NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int c = wm * MT * 16 + mi * 16 + fi;
+    xcol[mi] = XSWZ ? (c ^ (16 * (fg & 1))) : c;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int c = wn * NT * 16 + ni * 16 + fi;
+    zcol[ni] = ZSWZ ? (c ^ (16 * (fg & 1))) : c;
+  }
+
+  auto compute_chunk = [&](int buf) {
+    const float* Xb = Xs + buf * PK * BMc + fg * BMc;
+    const float* Zb = Zs + buf * PK * BNc + fg * BNc;
+#pragma unroll
+    for (int s = 0; s < PK / 4; ++s) {   // pixel p = 4*s + fg of the chunk
+      float xa[MT], zb[NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) xa[mi] = Xb[4 * s * BMc + xcol[mi]];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) zb[ni] = Zb[4 * s * BNc + zcol[ni]];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mi], zb[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  if (nchunks > 0) {
+    dma_chunk(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) dma_chunk(c + 1, (c + 1) & 1);
+      if (computing) compute_chunk(c & 1);
+      __syncthreads();
+    }
+  }
+
+  // D[row = ci][col = co]: lane holds rows 4*fg + r, column fi of each 16x16 tile
+  if (!computing) return;
+  float* dwt = a.dw + (size_t)tap * a.Ct * a.Cout;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int co = co0 + wn * NT * 16 + ni * 16 + fi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + wm * MT * 16 + mi * 16 + 4 * fg + r;
+        if (ci < a.Cx && co < a.Cout)
+          atomicAdd(dwt + (size_t)(a.ci_off + ci) * a.Cout + co, acc[mi][ni][r] * a.x_scale);
+      }
+    }
+}
+
+// VALU fallback: one block per (pixel slice); threads stride over (tap, ci, co).
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const WgradArgs a) {
+  const int p_begin = blockIdx.x * a.slice;
+  const int p_end = min(p_begin + a.slice, a.npix);
+  const int per_tap = a.Cx * a.Cout;
+  const int total = a.KH * a.KW * per_tap;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int tap = e / per_tap;
+    const int r = e - tap * per_tap;
+    const int ci = r / a.Cout, co = r - ci * a.Cout;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    float s = 0.f;
+    for (int p = p_begin; p < p_end; ++p) {
+      const int ow = p % a.Wo;
+      const int q = p / a.Wo;
+      const int oh = q % a.Ho;
+      const int n = q / a.Ho;
+      const int ih = oh * a.stride - a.pad_t + kh, iw = ow * a.stride - a.pad_l + kw;
+      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        s = fmaf(a.x[(size_t)((n * a.H + ih) * a.W + iw) * a.Cx + ci], a.dz[(size_t)p * a.Cout + co], s);
+    }
+    atomicAdd(a.dw + ((size_t)tap * a.Ct + a.ci_off + ci) * a.Cout + co, s * a.x_scale);
+  }
+}
+
+// Wt[kh][kw][co][ci - c_begin] = W[KH-1-kh][KW-1-kw][ci][co] * scale,  ci in [c_begin, c_begin+c_count)
+__global__ __launch_bounds__(256) void filter_transform_kernel(const float* __restrict__ w,
+                                                               float* __restrict__ wt, int KH, int KW,
+                                                               int Cin, int Cout, int c_begin,
+                                                               int c_count, float scale) {
+  const long total = (long)KH * KW * Cout * c_count;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int ci = (int)(e % c_count);
+    long t = e / c_count;
+    const int co = (int)(t % Cout);
+    t /= Cout;
+    const int kw = (int)(t % KW), kh = (int)(t / KW);
+    wt[e] = scale * w[(((long)(KH - 1 - kh) * KW + (KW - 1 - kw)) * Cin + c_begin + ci) * Cout + co];
+  }
+}
+
+// db[c] += sum over pixels of dz[p][c]; grid-stride over pixel blocks, one atomic per block and channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db,
+                                                        long npix, int C) {
+  __shared__ float part[256];
+  // thread = (channel lane, pixel lane): CL channels x PL pixel lanes, CL = min(C rounded to pow2, 256)
+  int CL = 1;
+  while (CL < C && CL < 256) CL <<= 1;
+  const int PL = 256 / CL;
+  const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+  for (int c0 = 0; c0 < C; c0 += CL) {
+    const int c = c0 + cl;
+    float s = 0.f;
+    if (c < C)
+      for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL) s += dz[p * C + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+      float tsum = s;
+      for (int j = 1; j < PL; ++j) tsum += part[j * CL + cl];
+      atomicAdd(db + c, tsum);
+    }
+    __syncthreads();
+  }
+}
+
+template <int BMc, int BNc, int WM, int WN>
+int launch_wgrad(WgradArgs& a, hipStream_t st) {
+  a.tiles_m = (a.Cx + BMc - 1) / BMc;
+  a.tiles_n = (a.Cout + BNc - 1) / BNc;
+  constexpr int lds = 2 * PK * (BMc + BNc) * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<BMc, BNc, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  // enough pixel slices to fill the chip ~4x, but at least 2048 pixels per slice to bound the atomics
+  const long tiles = (long)a.KH * a.KW * a.tiles_m * a.tiles_n;
+  long want = (256L * 8 + tiles - 1) / tiles;
+  long slice = (a.npix + want - 1) / want;
+  if (slice < 2048) slice = 2048;
+  slice = (slice + PK - 1) / PK * PK;
+  a.slice = (int)slice;
+  a.nslices = (int)((a.npix + slice - 1) / slice);
+  if (a.nslices > 65535) return shdr::fail(SHDR_E_SHAPE, "wgrad: too many pixel slices");
+  hipLaunchKernelGGL((wgrad_mfma_kernel<BMc, BNc, WM, WN>), dim3((unsigned)tiles, (unsigned)a.nslices), dim3(256),
+                     lds, st, a);
+  return shdr::check_launch("wgrad_mfma_kernel");
+}
+
+template <int BMc>
+int dispatch_n(WgradArgs& a, hipStream_t st) {
+  // (ci tile, co tile) -> computing-wave layout WM x WN; every tile divides its channel count
+  if (a.Cout % 128 == 0) return launch_wgrad<BMc, 128, (BMc >= 32 ? 2 : 1), (BMc >= 32 ? 2 : 4)>(a, st);
+  if (a.Cout % 64 == 0) return launch_wgrad<BMc, 64, (BMc >= 32 ? 2 : 1), (BMc >= 32 ? 2 : 4)>(a, st);
+  if (a.Cout % 32 == 0) return launch_wgrad<BMc, 32, (BMc >= 32 ? 2 : 1), 2>(a, st);
+  return launch_wgrad<BMc, 16, (BMc >= 64 ? 4 : BMc / 16), 1>(a, st);
+}
+
+}  // namespace
+
+extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, int which, const float* dz,
+                                     float* dw, void* stream) {
+  SHDR_REQUIRE(d && x && dz && dw, SHDR_E_NULL, "wgrad: null pointer");
+  SHDR_REQUIRE(which == 0 || which == 1, SHDR_E_SHAPE, "wgrad: which must be 0 (x1) or 1 (x2)");
+  SHDR_REQUIRE(which == 0 || d->C2 > 0, SHDR_E_SHAPE, "wgrad: no second source");
+  SHDR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
+                   d->stride > 0 && d->Ho > 0 && d->Wo > 0, SHDR_E_SHAPE, "wgrad: non-positive dimension");
+  SHDR_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31) && (long)d->N * d->H * d->W < (1L << 31), SHDR_E_SHAPE,
+               "wgrad: more than 2^31 pixels");
+  WgradArgs a{};
+  a.x = x; a.dz = dz; a.dw = dw;
+  a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cx = which ? d->C2 : d->C1;
+  a.Ct = d->C1 + d->C2;
+  a.ci_off = which ? d->C1 : 0;
+  a.Cout = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.Ho = d->Ho; a.Wo = d->Wo;
+  a.npix = d->N * d->Ho * d->Wo;
+  a.x_scale = which ? d->x2_scale : 1.0f;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool mfma_ok = (a.Cx % 16 == 0) && (a.Cout % 16 == 0) && shdr::aligned16(x) && shdr::aligned16(dz);
+  if (mfma_ok && d->algo != SHDR_ALGO_DIRECT) {
+    if (a.Cx % 128 == 0) return dispatch_n<128>(a, st);
+    if (a.Cx % 64 == 0) return dispatch_n<64>(a, st);
+    if (a.Cx % 32 == 0) return dispatch_n<32>(a, st);
+    return dispatch_n<16>(a, st);
+  }
+  SHDR_REQUIRE(d->algo != SHDR_ALGO_MFMA, SHDR_E_ALIGN, "wgrad: MFMA path needs Cin%%16==0 and Cout%%16==0");
+  a.slice = 1024;
+  a.nslices = (a.npix + a.slice - 1) / a.slice;
+  hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)a.nslices), dim3(256), 0, st, a);
+  return shdr::check_launch("wgrad_direct_kernel");
+}
+
+extern "C" int shdr_filter_transform_f32(const float* w, float* wt, int KH, int KW, int Cin, int Cout,
+                                         int c_begin, int c_count, float scale, void* stream) {
+  SHDR_REQUIRE(w && wt, SHDR_E_NULL, "filter_transform: null pointer");
+  SHDR_REQUIRE(KH > 0 && KW > 0 && Cin > 0 && Cout > 0 && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin,
+               SHDR_E_SHAPE, "filter_transform: bad shape");
+  const long total = (long)KH * KW * Cout * c_count;
+  hipLaunchKernelGGL(filter_transform_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, wt, KH, KW, Cin, Cout, c_begin, c_count, scale);
+  return shdr::check_launch("filter_transform");
+}
+
+extern "C" int shdr_bias_grad_f32(const float* dz, float* db, int64_t npix, int C, void* stream) {
+  SHDR_REQUIRE(dz && db, SHDR_E_NULL, "bias_grad: null pointer");
+  SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bias_grad: bad shape");
+  int CL = 1;
+  while (CL < C && CL < 256) CL <<= 1;
+  const int PL = 256 / CL;
+  long g = (npix + (long)PL * 64 - 1) / ((long)PL * 64);
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz,
+                     db, (long)npix, C);
+  return shdr::check_launch("bias_grad");
+}

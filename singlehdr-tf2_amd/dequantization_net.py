@@ -6,6 +6,8 @@ required arguments, `net(x, training=...)` on NHWC float32 in [0,1],
 `tanh` head added to the input.  `training` is ignored (no BatchNorm), as in
 the reference.  All arithmetic runs in the libshdr HIP kernels.
 """
+import torch
+
 try:
     from . import _ops as K
     from ._layers import Layer, Conv2D
@@ -83,5 +85,7 @@ class model(_unet):
 
     def call(self, input_images, training="training"):
         x = self._trunk(input_images)
+        if x.requires_grad and torch.is_grad_enabled():   # taped: the residual add is a separate op
+            return K.add(self.out.call_padded(x, cout_pad=16, act1=K.ACT_TANH), input_images)
         # tanh(out(x)) + input  (dequantization_net.py:62-63) fused into the conv epilogue
         return self.out.call_padded(x, cout_pad=16, act1=K.ACT_TANH, residual=input_images)

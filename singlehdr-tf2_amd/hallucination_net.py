@@ -6,19 +6,14 @@ decoder with BatchNorm, 1x1 skip fusers.  Input NHWC float32 RGB in [0,1]
 libshdr HIP kernels; inference BatchNorm, bias, relu, the sk/255 scaling and the
 channel concat are fused into the convolution.
 """
+import torch
+
 try:
     from . import _ops as K
     from ._layers import Layer, Conv2D, BatchNormalization, is_training
 except ImportError:
     import _ops as K
     from _layers import Layer, Conv2D, BatchNormalization, is_training
-
-
-def _no_train(training):
-    if is_training(training):
-        raise NotImplementedError(
-            "training-mode BatchNormalization (batch statistics + backward) is not built yet on the "
-            "HIP path; call with training=False")
 
 
 class down1(Layer):
@@ -64,8 +59,9 @@ class up(Layer):
         self.norm1 = BatchNormalization(outChannels, device=device)
 
     def call(self, x, training="training"):
-        _no_train(training)
         x = K.resize2x(x)
+        if is_training(training):       # relu(conv) -> batch-statistics BN -> relu, separate taped ops
+            return self.norm1.train_apply(self.conv1(x, act1=K.ACT_RELU), relu=True)
         scale, shift = self.norm1.folded()
         return self.conv1(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
 
@@ -79,7 +75,7 @@ class skipLayer(Layer):
 
     def call(self, x, sk, **kw):
         c1 = x.shape[-1]
-        if c1 % 4 == 0 and sk.shape[-1] % 4 == 0:
+        if c1 % 4 == 0 and sk.shape[-1] % 4 == 0 and not (torch.is_grad_enabled() and self.conv1.kernel.requires_grad):
             # fold the 1/255 into the sk rows of the filter (cached) -> LDS-DMA conv kernel
             return K.conv2d(x, self.conv1.kernel_x2_scaled(c1, 1.0 / 255), self.conv1.bias, x2=sk, **kw)
         return self.conv1(x, x2=sk, x2_scale=1.0 / 255, **kw)
@@ -111,7 +107,7 @@ class model(Layer):
         self.s0 = skipLayer(3, 3, 3, device=device)
 
     def call(self, input_layer, training="training"):
-        _no_train(training)
+        train = is_training(training)
         if list(self.VGG_MEAN) != [103.939, 116.779, 123.68]:
             raise NotImplementedError("custom VGG_MEAN is not supported by the HIP preprocess kernel")
         bgr = K.vgg_preprocess(input_layer)          # x*255, RGB->BGR, - mean  (:149-153)
@@ -120,13 +116,19 @@ class model(Layer):
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)
         enc, d5 = self.d5(x)
-        sc, sh = self.norm1.folded()
-        x = self.conv1(enc, scale=sc, shift=sh, act2=K.ACT_RELU)   # conv -> BN -> relu (:163-165)
+        if train:
+            x = self.norm1.train_apply(self.conv1(enc), relu=True)
+        else:
+            sc, sh = self.norm1.folded()
+            x = self.conv1(enc, scale=sc, shift=sh, act2=K.ACT_RELU)   # conv -> BN -> relu (:163-165)
         x = self.s5(self.u5(x, training), d5)
         x = self.s4(self.u4(x, training), d4)
         x = self.s3(self.u3(x, training), d3)
         x = self.s2(self.u2(x, training), d2)
         x = self.s1(self.u1(x, training), d1)
-        sc, sh = self.norm2.folded()
-        x = self.conv2.call_padded(x, cout_pad=16, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:183-185)
+        if train:
+            x = self.norm2.train_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
+        else:
+            sc, sh = self.norm2.folded()
+            x = self.conv2.call_padded(x, cout_pad=16, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:183-185)
         return self.s0(x, bgr, act1=K.ACT_RELU)                    # relu(s0(x, bgr)) (:188-190)

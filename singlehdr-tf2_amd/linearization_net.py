@@ -28,14 +28,17 @@ FRONTEND_CHANNELS = 93          # linearization_net.py:322
 FRONTEND_CHANNELS_PADDED = 96   # MFMA-friendly (3 x 32-channel chunks)
 
 
-def _no_train(training):
+def _conv_bn(conv, norm, x, relu, residual=None, cin_pad=None, training=False):
+    """conv -> BatchNorm [-> + residual] [-> relu].
+
+    inference: one kernel (BN folded into the conv epilogue, residual and relu fused);
+    training : conv, batch-statistics BN (+relu), residual join relu(a + b) as separate taped ops."""
     if is_training(training):
-        raise NotImplementedError(
-            "training-mode BatchNormalization (batch statistics + backward) is not built yet on the "
-            "HIP path; call with training=False")
-
-
-def _conv_bn(conv, norm, x, relu, residual=None, cin_pad=None):
+        z = conv(x) if cin_pad is None else conv.call_padded(x, cin_pad=cin_pad)
+        if residual is None:
+            return norm.train_apply(z, relu=relu)
+        y = norm.train_apply(z, relu=False)
+        return K.AUTOGRAD.add_relu(residual, y) if relu else K.add(residual, y)
     scale, shift = norm.folded()
     w = conv.kernel if cin_pad is None else conv.kernel_padded(cin_pad)
     return K.conv2d(x, w, conv.bias, stride=conv.strides, scale=scale, shift=shift, residual=residual,
@@ -58,11 +61,11 @@ class resBlock_type1(Layer):
         self.norm4 = BatchNormalization(branch2_filters[2], device=device)
 
     def call(self, x, training="training"):
-        _no_train(training)
-        norm1 = _conv_bn(self.conv1, self.norm1, x, relu=False)
-        act2 = _conv_bn(self.conv2, self.norm2, x, relu=True)
-        act3 = _conv_bn(self.conv3, self.norm3, act2, relu=True)
-        return _conv_bn(self.conv4, self.norm4, act3, relu=True, residual=norm1)  # relu(norm1 + norm4)
+        t = training
+        norm1 = _conv_bn(self.conv1, self.norm1, x, relu=False, training=t)
+        act2 = _conv_bn(self.conv2, self.norm2, x, relu=True, training=t)
+        act3 = _conv_bn(self.conv3, self.norm3, act2, relu=True, training=t)
+        return _conv_bn(self.conv4, self.norm4, act3, relu=True, residual=norm1, training=t)  # relu(norm1 + norm4)
 
 
 class resBlock_type2(Layer):
@@ -78,10 +81,10 @@ class resBlock_type2(Layer):
         self.norm3 = BatchNormalization(filters[2], device=device)
 
     def call(self, x, training="training"):
-        _no_train(training)
-        act1 = _conv_bn(self.conv1, self.norm1, x, relu=True)
-        act2 = _conv_bn(self.conv2, self.norm2, act1, relu=True)
-        return _conv_bn(self.conv3, self.norm3, act2, relu=True, residual=x)  # relu(x + norm3)
+        t = training
+        act1 = _conv_bn(self.conv1, self.norm1, x, relu=True, training=t)
+        act2 = _conv_bn(self.conv2, self.norm2, act1, relu=True, training=t)
+        return _conv_bn(self.conv3, self.norm3, act2, relu=True, residual=x, training=t)  # relu(x + norm3)
 
 
 class crfFeatureNet(Layer):
@@ -99,10 +102,9 @@ class crfFeatureNet(Layer):
 
     def call(self, ldr, training="training"):
         """`ldr` is the front-end tensor with 93 or (zero-padded) 96 channels."""
-        _no_train(training)
         cin = ldr.shape[-1]
         x = _conv_bn(self.conv1, self.norm1, ldr, relu=True,
-                     cin_pad=None if cin == FRONTEND_CHANNELS else cin)
+                     cin_pad=None if cin == FRONTEND_CHANNELS else cin, training=training)
         x = K.maxpool3s2(x)
         x = self.res1(x, training)
         x = self.res2(x, training)
@@ -161,7 +163,6 @@ class model(Layer):
         self.ae_invcrf_decode_net = AEInvcrfDecodeNet(device=device)
 
     def call(self, img, training="training"):
-        _no_train(training)
         feat_in = K.lin_frontend(img, FRONTEND_CHANNELS_PADDED)   # linearization_net.py:312-322, fused
         feature = self.crf_feature_net(feat_in, training)
         invcrf = self.ae_invcrf_decode_net(feature)

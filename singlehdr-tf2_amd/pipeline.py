@@ -3,6 +3,10 @@
 `inference` follows test_real_refinement.py:86-110 of the reference
 (deq -> clip -> lin -> apply_rf -> alpha -> hal -> blend -> ref).
 """
+import math
+
+import torch
+
 try:
     from . import _ops as K
     from . import tf_utils
@@ -21,6 +25,10 @@ class Inference:
         self.threshold = threshold
 
     def __call__(self, ldr, return_intermediates=False):
+        with torch.no_grad():
+            return self._run(ldr, return_intermediates)
+
+    def _run(self, ldr, return_intermediates):
         pred_deq = self._deq(ldr, training=False)
         C_pred = K.clip(pred_deq, 0.0, 1.0)
         pred_invcrf = self._lin(C_pred, training=False)
@@ -35,4 +43,118 @@ class Inference:
         if return_intermediates:
             return dict(C_pred=C_pred, invcrf=pred_invcrf, B_pred=B_pred, hal=bgr_hal_res, A_pred=A_pred,
                         hdr=out if self._ref is not None else None)
+        return out
+
+
+# ---------------------------------------------------------------------------
+# joint training step (joint_training.py:137-194)
+# ---------------------------------------------------------------------------
+class FlatParams:
+    """All trainable variables of several models as views of ONE flat fp32 buffer (plus flat grad / Adam
+    moment buffers): one Adam kernel and one RCCL all-reduce per step instead of one per variable."""
+
+    def __init__(self, models):
+        self.variables = []
+        for m in models:
+            self.variables += m.trainable_variables            # joint_training.py:185 order
+        n = sum(v.numel() for v in self.variables)
+        dev = self.variables[0].device
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        with torch.no_grad():
+            for v in self.variables:
+                k = v.numel()
+                self.flat[o:o + k].copy_(v.detach().reshape(-1))
+                v.data = self.flat[o:o + k].view(v.shape)       # the variable now aliases the flat buffer
+                v.grad = self.grad[o:o + k].view(v.shape)       # autograd accumulates in place
+                o += k
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class KerasAdam:
+    """tf.keras.optimizers.Adam(lr): beta 0.9/0.999, epsilon 1e-7,
+    theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)   (SURVEY.md section 8c item 10)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.p, self.lr, self.b1, self.b2, self.eps, self.t = params, lr, beta1, beta2, eps, 0
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        K.adam_step(self.p.flat, self.p.grad, self.p.m, self.p.v, lr_t, self.b1, self.b2, self.eps, grad_scale)
+
+
+class JointTrainStep:
+    """The `train_step(ds, invcrf)` closure of joint_training.py:137-194.
+
+    deq, lin and hal are fed ground-truth intermediates (jpeg, ldr, clipped_hdr_t); the loss is
+    per-sample [b] and its SUM over the batch is differentiated (tape.gradient of a non-scalar).
+    Data parallel: weights replicated, batch sharded, ONE all_reduce(SUM) of the flat
+    gradient over RCCL; BatchNorm statistics are per replica; the batch-global TV mean is made exact by a
+    scalar all-reduce of sum(loss_mask)."""
+
+    LEARNING_RATE = 1e-5   # joint_training.py:20
+    THRESHOLD = 0.12       # joint_training.py:140
+
+    def __init__(self, deq, lin, hal, vgg, vgg2=None, lr=None, process_group=None, world_size=1):
+        self._deq, self._lin, self._hal, self._vgg, self._vgg2 = deq, lin, hal, vgg, vgg2 or vgg
+        self.params = FlatParams([deq, lin, hal])
+        self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
+        self.pg, self.world = process_group, world_size
+
+    def losses(self, ds, invcrf):
+        ldr, jpeg_img_float, clipped_hdr_t, hdr_t, loss_mask = ds
+        mask = loss_mask.reshape(-1)
+        thr = self.THRESHOLD
+        alpha = K.alpha_mask(clipped_hdr_t, thr)
+
+        # Dequantization (:150-153)
+        pred_deq = self._deq(jpeg_img_float, training=True)
+        C_pred = K.clip(pred_deq, 0.0, 1.0)
+        loss_deq = K.diff_loss(C_pred, ldr, 0) * mask
+
+        # Linearization (:156-160)
+        pred_invcrf = self._lin(ldr, training=True)
+        B_pred = tf_utils.apply_rf(ldr, pred_invcrf)
+        crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
+        loss_lin = (10.0 * K.diff_loss(B_pred, clipped_hdr_t, 0) + crf_loss) * mask
+
+        # Hallucination (:163-182)
+        bgr_pred_hal = self._hal(clipped_hdr_t, training=True)
+        A_pred = K.blend_const(clipped_hdr_t, alpha, bgr_pred_hal, thr)      # clipped + alpha * bgr2rgb(hal)
+        y_final_gamma = K.logc(A_pred)
+        with torch.no_grad():
+            hdr_t_gamma = K.logc(hdr_t)
+            target_feats = self._vgg2(hdr_t_gamma)
+        feats = self._vgg(y_final_gamma)
+        perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
+        l1loss_hal = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
+        tv_loss = K.tv_loss(y_final_gamma)                                     # batch-global scalar [1]
+        tv_w = mask
+        if self.pg is not None and self.world > 1:
+            # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
+            import torch.distributed as dist
+            msum = mask.sum()
+            dist.all_reduce(msum, group=self.pg)
+            tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
+        loss_hal = (l1loss_hal + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
+        total_loss = loss_deq + loss_lin + loss_hal
+        return dict(total=total_loss, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal, crf_loss=crf_loss,
+                    C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)
+
+    def __call__(self, ds, invcrf, apply=True):
+        self.params.zero_grad()
+        out = self.losses(ds, invcrf)
+        out["total"].sum().backward()                     # gradient of the batch-summed loss
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)   # the ONE gradient collective
+        if apply:
+            self.optimizer.step()
         return out

@@ -7,6 +7,8 @@ relu(input[..., 0:3] + conv).  `training` is ignored (no BatchNorm).
 The input may also be given zero-padded to 12 channels ([A, B, C, 0]): the first
 7x7 conv then runs on the MFMA tile instead of the VALU fallback.
 """
+import torch
+
 try:
     from . import _ops as K
     from .dequantization_net import _unet, down, up  # noqa: F401  (same blocks, refinement_net.py:4-29)
@@ -21,5 +23,8 @@ class model(_unet):
 
     def call(self, input_images, training="training"):
         x = self._trunk(input_images)
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("Refinement-Net backward (finetune_real_dataset.py:144-183) is not built yet: "
+                                      "call under torch.no_grad()")
         # relu(input[..., 0:3] + out(x))  (refinement_net.py:63-66): residual read with channel stride 9
         return self.out.call_padded(x, cout_pad=16, residual=input_images, act2=K.ACT_RELU)

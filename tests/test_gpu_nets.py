@@ -41,9 +41,12 @@ def test_refinement_net_parity(shdr):
     m, p = build(shdr, "ref", 22)
     x = np.random.default_rng(2).random((1, 64, 64, 9))
     ref = nets.ref_forward(p, x)
-    assert rel_err(host(m(dev(x), training=False)), ref) <= TOL                      # 9-channel input (reference surface)
-    x12 = np.concatenate([x, np.zeros((1, 64, 64, 3))], -1)
-    assert rel_err(host(m(dev(x12), training=False)), ref) <= TOL                    # zero-padded fast path
+    with torch.no_grad():
+        assert rel_err(host(m(dev(x), training=False)), ref) <= TOL                  # 9-channel input (reference surface)
+        x12 = np.concatenate([x, np.zeros((1, 64, 64, 3))], -1)
+        assert rel_err(host(m(dev(x12), training=False)), ref) <= TOL                # zero-padded fast path
+    with pytest.raises(NotImplementedError):
+        m(dev(x), training=True)                                                     # backward of ref: next round
 
 
 def test_hallucination_net_parity(shdr):
