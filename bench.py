@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed joint-training steps (0 = skip that leg)")
+    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-size", type=int, default=256)
     return ap.parse_args()
 
 
@@ -206,6 +209,57 @@ def main():
             "sample": "1 image %dx%d deq+lin+hal, float32 NumPy/BLAS oracle (proxy for TF2-CPU, which is not "
                       "installable here), %.1f s" % (args.size, args.size, cpu_dt),
             "gpu_vs_oracle_rel_err": float("%.3g" % err),
+        }
+
+    # ---- joint-training leg (BASELINE configs[3]): deq+lin+hal + VGG16 perceptual loss, fwd+bwd+Adam, batch 32 x
+    #      256x256 per GPU, ONE RCCL all-reduce(SUM) of the flat fp32 gradient per step (weak scaling) ------------
+    if args.train_steps > 0:
+        del out
+        torch.cuda.empty_cache()
+        tg = torch.Generator().manual_seed(4 + rank)
+        b, sz = args.train_batch, args.train_size
+
+        def q(shape):
+            return torch.round(torch.rand(shape, generator=tg) * 255.0) / 255.0
+
+        clipped = q((b, sz, sz, 3))
+        sat = clipped >= 1.0
+        hdr_t = torch.where(sat, clipped * (1.0 + 3.0 * torch.rand((b, sz, sz, 3), generator=tg)), clipped)
+        inv = torch.cumsum(torch.rand((b, 1024), generator=tg), dim=1)
+        inv = (inv - inv[:, :1]) / (inv[:, -1:] - inv[:, :1])
+        ds = tuple(t.cuda() for t in (q((b, sz, sz, 3)), q((b, sz, sz, 3)), clipped, hdr_t, torch.ones(b, 1, 1, 1)))
+        inv = inv.cuda()
+        vg = torch.Generator().manual_seed(99)
+        dd = {}
+        for name, cin, cout in (("conv1_1", 3, 64), ("conv1_2", 64, 64), ("conv2_1", 64, 128), ("conv2_2", 128, 128),
+                                ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256)):
+            lim = (6.0 / (9 * cin + 9 * cout)) ** 0.5
+            dd[name] = [((torch.rand((3, 3, cin, cout), generator=vg) * 2 - 1) * lim).numpy(), torch.zeros(cout).numpy()]
+        vgg = pkg.vgg16.Vgg16(data_dict=dd)
+        step = pkg.pipeline.JointTrainStep(deq, lin, hal, vgg, process_group=(dist.group.WORLD if dist is not None else None),
+                                           world_size=world)
+        step(ds, inv)                      # warm-up (allocator, kernel attributes, RCCL rings)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tout = step(ds, inv)
+        barrier()
+        tdt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([tdt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        loss = float(tout["total"].detach().sum())
+        assert loss == loss, "joint step produced NaN"
+        # algorithmic FLOPs per image: fwd 102.1 + 2 x VGG 24.39, bwd 2 x 102.1 + 24.39 GF at 256^2
+        gflop_img = 379.5 * (sz / 256.0) ** 2
+        result["joint_train"] = {
+            "workload": "BASELINE configs[3]: joint_training.py step, batch=%d x %dx%d per GPU, fp32, "
+                        "1 all-reduce(SUM) of %d fp32 gradients" % (b, sz, sz, step.params.num_params),
+            "ms_per_step": round(tdt / args.train_steps * 1e3, 2), "steps": args.train_steps,
+            "images_per_s": round(b * world * args.train_steps / tdt, 2), "n_gpus": world, "scaling": "weak",
+            "tflops_algorithmic_per_gpu": round(gflop_img * b * args.train_steps / tdt / 1e3, 2),
+            "loss": round(loss, 5),
         }
 
     if rank == 0:

@@ -53,25 +53,32 @@ class FlatParams:
     """All trainable variables of several models as views of ONE flat fp32 buffer (plus flat grad / Adam
     moment buffers): one Adam kernel and one RCCL all-reduce per step instead of one per variable."""
 
+    ALIGN = 64
+
     def __init__(self, models):
         self.variables = []
         for m in models:
             self.variables += m.trainable_variables            # joint_training.py:185 order
-        n = sum(v.numel() for v in self.variables)
+        # every variable starts on a 64-float (256-byte) boundary: the kernels read filters, biases and
+        # BN vectors with 16-byte vector / LDS-DMA loads.  The gaps stay zero (zero gradient -> Adam no-op).
+        self.offsets = []
+        n = 0
+        for v in self.variables:
+            self.offsets.append(n)
+            n += (v.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         dev = self.variables[0].device
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
-        o = 0
         with torch.no_grad():
-            for v in self.variables:
+            for v, o in zip(self.variables, self.offsets):
                 k = v.numel()
                 self.flat[o:o + k].copy_(v.detach().reshape(-1))
                 v.data = self.flat[o:o + k].view(v.shape)       # the variable now aliases the flat buffer
                 v.grad = self.grad[o:o + k].view(v.shape)       # autograd accumulates in place
-                o += k
-        self.numel = n
+        self.numel = n                                          # padded length of the flat buffers
+        self.num_params = sum(v.numel() for v in self.variables)
 
     def zero_grad(self):
         self.grad.zero_()

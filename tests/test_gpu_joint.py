@@ -1,0 +1,101 @@
+"""GPU tests of the joint training step (joint_training.py:137-194) against the float64 reference."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+from conftest import quantised_image, rel_err
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def make_batch(rng, b, s):
+    """SURVEY.md section 8d config 4 input law"""
+    clipped = quantised_image(rng, (b, s, s, 3))
+    clipped[0, :10, :10] = 1.0                                  # saturated patch: alpha mask active
+    hdr_t = clipped * np.where(clipped >= 1.0, 1 + 3 * rng.random((b, s, s, 3)), 1.0)
+    inv = np.cumsum(rng.random((b, 1024)), axis=1)
+    inv = (inv - inv[:, :1]) / (inv[:, -1:] - inv[:, :1])
+    mask = np.ones((b, 1, 1, 1))
+    mask[-1] = 0.0                                              # one masked sample
+    return (quantised_image(rng, (b, s, s, 3)), quantised_image(rng, (b, s, s, 3)), clipped, hdr_t, mask), inv
+
+
+@pytest.fixture(scope="module")
+def setup(shdr, emor_table):
+    rng = np.random.default_rng(11)
+    P = {k: nets.init_params(getattr(nets, k + "_spec")(), 70 + i) for i, k in enumerate(("deq", "lin", "hal"))}
+    V = nets.init_params(nets.vgg_spec(), 73)
+    batch, inv = make_batch(rng, 3, 64)
+    ms = {"deq": shdr.dequantization_net.model().load_numpy(P["deq"]),
+          "lin": shdr.linearization_net.model().load_numpy(P["lin"]),
+          "hal": shdr.hallucination_net.model().load_numpy(P["hal"])}
+    dd = {n: [V[n + ".kernel"], V[n + ".bias"]] for n in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3")}
+    vgg = shdr.vgg16.Vgg16(data_dict=dd)
+    step = shdr.pipeline.JointTrainStep(ms["deq"], ms["lin"], ms["hal"], vgg, lr=1e-3)
+    tP = {k: R.params_to_torch(v) for k, v in P.items()}
+    ref = R.joint_losses(tP, R.params_to_torch(V, False), tuple(R.T(t) for t in batch), R.T(inv), emor_table)
+    ref["total"].sum().backward()
+    return dict(step=step, models=ms, batch=tuple(dev(t) for t in batch), inv=dev(inv), ref=ref, tP=tP, P=P)
+
+
+def test_joint_losses_match_reference(setup):
+    out = setup["step"](setup["batch"], setup["inv"], apply=False)
+    for k in ("loss_deq", "loss_lin", "loss_hal", "total"):
+        assert rel_err(host(out[k]), setup["ref"][k].detach().numpy()) <= 1e-4, k
+    assert float(out["total"][-1]) == 0.0                       # masked sample contributes nothing but TV*0
+    for k in ("C_pred", "B_pred", "A_pred"):
+        assert rel_err(host(out[k]), setup["ref"][k].detach().numpy()) <= 1e-4, k
+
+
+def test_joint_gradients_and_flat_buffer(setup):
+    step = setup["step"]
+    step(setup["batch"], setup["inv"], apply=False)
+    assert step.params.num_params == 27741644                   # deq+lin+hal trainable parameters
+    worst = 0.0
+    for net in ("deq", "lin", "hal"):
+        got = np.concatenate([host(t.grad).ravel() for t in setup["models"][net].trainable_variables]).astype(np.float64)
+        ref = np.concatenate([setup["tP"][net][n].grad.numpy().ravel() for n, _, tr in setup["models"][net].named_weights() if tr])
+        worst = max(worst, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    assert worst <= 5e-2, worst                                  # see test_gpu_grad.NET_L2_TOL
+    # the flat gradient buffer holds exactly these gradients (alignment gaps stay zero)
+    assert abs(float(step.params.grad.double().abs().sum()) -
+               sum(float(t.grad.double().abs().sum()) for m in setup["models"].values() for t in m.trainable_variables)) <= 1e-6 * float(step.params.grad.double().abs().sum())
+    assert all(t.data_ptr() % 16 == 0 and t.grad.data_ptr() % 16 == 0 for m in setup["models"].values() for t in m.trainable_variables)
+    # variables alias the flat buffers (one Adam kernel / one all-reduce per step)
+    v0 = setup["models"]["deq"].trainable_variables[0]
+    assert v0.data_ptr() == step.params.flat.data_ptr() and v0.grad.data_ptr() == step.params.grad.data_ptr()
+
+
+def test_keras_adam_update(setup):
+    step = setup["step"]
+    step(setup["batch"], setup["inv"], apply=False)
+    p0, g = host(step.params.flat).astype(np.float64), host(step.params.grad).astype(np.float64)
+    m0, v0, t0 = host(step.params.m).astype(np.float64), host(step.params.v).astype(np.float64), step.optimizer.t
+    step.optimizer.step()
+    t = t0 + 1
+    m = 0.9 * m0 + 0.1 * g
+    v = 0.999 * v0 + 0.001 * g * g
+    lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    expect = p0 - lr_t * m / (np.sqrt(v) + 1e-7)                 # Keras epsilon placement
+    np.testing.assert_allclose(host(step.params.flat), expect, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(host(step.params.m), m, rtol=1e-5, atol=1e-12)
+
+
+def test_training_reduces_the_loss(setup):
+    step = setup["step"]
+    first = float(step(setup["batch"], setup["inv"])["total"].sum())
+    for _ in range(4):
+        last = float(step(setup["batch"], setup["inv"])["total"].sum())
+    assert np.isfinite(last) and last < first, (first, last)
