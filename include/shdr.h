@@ -165,6 +165,8 @@ int shdr_alpha_blend_fwd_f32(const float* b, const float* hal, float* a, float* 
  * (test_real_refinement.py:108). */
 int shdr_pack3_fwd_f32(const float* s0, const float* s1, const float* s2, const float* s3,
                        int nsrc, float* y, int out_channels, int64_t npix, void* stream);
+/* y[p][c] = c < Cin ? x[p][c] : 0 for c < Cout (zero channel padding for the MFMA / DMA tiles). */
+int shdr_pad_channels_f32(const float* x, float* y, int64_t npix, int Cin, int Cout, void* stream);
 /* log(1+10x)/log(11) (joint_training.py:166,173). */
 int shdr_logc_fwd_f32(const float* x, float* y, int64_t n, void* stream);
 

@@ -31,11 +31,17 @@ def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
     cout_real = dz.shape[3]
     if w.shape[3] != cout_real:                       # zero-padded filter columns carry no gradient
         w = w[..., :cout_real].contiguous()
-    wt = K.filter_transform(w, c_begin, c_count, scale)
+    wt = K.filter_transform(w, c_begin, c_count, scale)        # [kh, kw, cout_real, c_count]
+    # narrow tensors (3-channel heads, 3/4-channel images) are zero-padded onto the MFMA tile
+    cin_pad = (-cout_real) % 4
+    cout_pad = (-c_count) % 16
+    if cin_pad or cout_pad:
+        wt = F.pad(wt, (0, cout_pad, 0, cin_pad))
+        dz = K.pad_channels(dz, cout_real + cin_pad)
     if stride == 1:
-        return K.conv2d(dz, wt)
+        return K.conv2d(dz, wt, cout_valid=c_count)
     if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
-        return K.upsample_zero2(K.conv2d(dz, wt), x_shape)
+        return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=c_count), x_shape)
     raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built "
                               "(on the hot path only first layers are strided, and they take data)" % (kh, kw, stride))
 

@@ -330,12 +330,41 @@ def _conv_desc(x_shape, w_shape, stride, c2, x2_scale, cout_valid):
     return d
 
 
+def pad_channels(x, channels):
+    """zero-pad the channel axis to `channels` (no-op if already that wide)"""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    c = x.shape[-1]
+    if c == channels:
+        return x
+    y = torch.empty(tuple(x.shape[:-1]) + (channels,), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_pad_channels_f32(_ptr(x), _ptr(y), x.numel() // c, c, channels, _stream()), "shdr_pad_channels_f32")
+    return y
+
+
+def _up16(c):
+    return (c + 15) // 16 * 16
+
+
 def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
-    """dW [kh,kw,C1+C2,Cout] of conv(concat[x, x2_scale*x2], W) given dz = dL/d(conv output)."""
+    """dW [kh,kw,C1+C2,Cout] of conv(concat[x, x2_scale*x2], W) given dz = dL/d(conv output).
+
+    Channel counts that are not multiples of 16 (3/4-channel images, 3-channel heads) are zero-padded so
+    that the layer runs on the MFMA weight-gradient tiles; the true rows / columns are sliced out."""
+    kh, kw, cin, cout = w_shape
+    c1 = x.shape[3]
+    c2 = 0 if x2 is None else x2.shape[3]
+    if c1 % 16 or c2 % 16 or cout % 16:
+        c1p, c2p, coutp = _up16(c1), (_up16(c2) if c2 else 0), _up16(cout)
+        dwp = conv2d_wgrad(pad_channels(x, c1p), None if x2 is None else pad_channels(x2, c2p), pad_channels(dz, coutp),
+                           (kh, kw, c1p + c2p, coutp), stride, x2_scale)
+        if c2:
+            return torch.cat([dwp[:, :, :c1, :cout], dwp[:, :, c1p:c1p + c2, :cout]], dim=2).contiguous()
+        return dwp[:, :, :c1, :cout].contiguous()
     lib = _lib.load()
     x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
-    c2 = 0 if x2 is None else _chk(_d(x2), "x2").shape[3]
-    kh, kw, cin, cout = w_shape
+    if x2 is not None:
+        _chk(_d(x2), "x2")
     if cin != x.shape[3] + c2 or cout != dz.shape[3]:
         raise ValueError("conv2d_wgrad: filter %s does not match x %s (+%d) / dz %s"
                          % (tuple(w_shape), tuple(x.shape), c2, tuple(dz.shape)))

@@ -79,7 +79,27 @@ __global__ __launch_bounds__(256) void pack3_kernel(Pack3Args src, int nsrc, flo
   }
 }
 
+// y[p][c] = c < Cin ? x[p][c] : 0, c < Cout (channel zero-padding so that narrow tensors fit the
+// 16-byte DMA quads / 16-channel MFMA tiles)
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long npix, int Cin, int Cout) {
+  const long total = npix * Cout;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / Cout;
+    const int c = (int)(e - p * Cout);
+    y[e] = c < Cin ? x[p * Cin + c] : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int shdr_pad_channels_f32(const float* x, float* y, int64_t npix, int Cin, int Cout, void* stream) {
+  SHDR_REQUIRE(x && y, SHDR_E_NULL, "pad_channels: null pointer");
+  SHDR_REQUIRE(npix > 0 && Cin > 0 && Cout >= Cin, SHDR_E_SHAPE, "pad_channels: need Cout >= Cin > 0");
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(shdr::stream_grid(npix * Cout)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, (long)npix, Cin, Cout);
+  return shdr::check_launch("pad_channels");
+}
 
 extern "C" int shdr_clip_fwd_f32(const float* x, float* y, int64_t n, float lo, float hi, void* stream) {
   SHDR_REQUIRE(x && y, SHDR_E_NULL, "clip: null pointer");
