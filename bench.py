@@ -179,9 +179,21 @@ def main():
         achieved = fl / sec / 1e12
         conv_total_flops = sum(a[0] for a in agg.values()) / reps
         conv_total_sec = sum(a[1] for a in agg.values()) / reps
+        # HBM bytes per launch of the dominant kernel: PMC counters collected offline (rocprofv3 cannot profile
+        # the process it runs in) with the same workload -- see profiles/r01_traffic.json for the recipe
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tk = json.load(f)["kernels"]
+            key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
+            hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
+            traffic = hits[0] if hits else None
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
             "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv": {"tflops": round(conv_total_flops / conv_total_sec / 1e12, 2),

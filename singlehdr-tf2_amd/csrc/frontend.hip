@@ -84,31 +84,30 @@ __device__ __forceinline__ float frontend_channel(const float* __restrict__ img,
   return soft_bin(rgb[c], bin + 1, (float)(2 * B), (float)B, 1.0f / (float)B);
 }
 
+// grid.y = image row (n*H + h), grid.x covers the W * QPP quads of that row: no runtime division
+// per thread (QPP is a compile-time constant), the 3 rows of the sobel stencil are block-uniform.
+template <int YC>
 __global__ __launch_bounds__(256) void lin_frontend_kernel(const float* __restrict__ img,
-                                                           float* __restrict__ y, int N, int H,
-                                                           int W, int YC) {
-  const int Q = (YC + 3) >> 2;
-  const long npix = (long)N * H * W;
-  const long total = npix * Q;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long p = e / Q;
-    const int ch0 = (int)(e - p * Q) * 4;
-    const int w = (int)(p % W);
-    const long t = p / W;
-    const int h = (int)(t % H);
-    const long ibase = (t / H) * (long)H * W;
-    const float rgb[3] = {img[p * 3], img[p * 3 + 1], img[p * 3 + 2]};
-    float v[4];
+                                                           float* __restrict__ y, int N, int H, int W) {
+  constexpr int QPP = (YC + 3) / 4;   // quads per pixel
+  const int row = blockIdx.y;
+  const int h = row % H;
+  const long ibase = (long)(row / H) * H * W;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * QPP) return;
+  const int w = idx / QPP, ch0 = (idx - w * QPP) * 4;
+  const long p = ibase + (long)h * W + w;
+  const float rgb[3] = {img[p * 3], img[p * 3 + 1], img[p * 3 + 2]};
+  float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = frontend_channel(img, ibase, h, w, H, W, rgb, ch0 + k);
-    float* yp = y + p * YC + ch0;
-    if ((YC & 3) == 0) {
-      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+  for (int k = 0; k < 4; ++k) v[k] = frontend_channel(img, ibase, h, w, H, W, rgb, ch0 + k);
+  float* yp = y + p * YC + ch0;
+  if ((YC & 3) == 0) {
+    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (ch0 + k < YC) yp[k] = v[k];
-    }
+    for (int k = 0; k < 4; ++k)
+      if (ch0 + k < YC) yp[k] = v[k];
   }
 }
 
@@ -139,9 +138,11 @@ extern "C" int shdr_lin_frontend_fwd_f32(const float* img, float* y, int N, int 
   SHDR_REQUIRE(N > 0 && H >= 2 && W >= 2, SHDR_E_SHAPE, "lin_frontend: need N>0, H,W>=2 (REFLECT pad)");
   SHDR_REQUIRE(y_channels >= 93, SHDR_E_SHAPE, "lin_frontend: y_channels must be >= 93");
   SHDR_REQUIRE((y_channels & 3) != 0 || shdr::aligned16(y), SHDR_E_ALIGN, "lin_frontend: y not 16-byte aligned");
+  SHDR_REQUIRE(y_channels == 93 || y_channels == 96, SHDR_E_SHAPE, "lin_frontend: y_channels must be 93 or 96");
+  SHDR_REQUIRE((long)N * H <= 65535, SHDR_E_SHAPE, "lin_frontend: N*H must be <= 65535");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const long total = (long)N * H * W * ((y_channels + 3) >> 2);
-  hipLaunchKernelGGL(lin_frontend_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, img, y, N,
-                     H, W, y_channels);
+  const dim3 grid((unsigned)((W * 24 + 255) / 256), (unsigned)(N * H));
+  if (y_channels == 96) hipLaunchKernelGGL(lin_frontend_kernel<96>, grid, dim3(256), 0, st, img, y, N, H, W);
+  else hipLaunchKernelGGL(lin_frontend_kernel<93>, grid, dim3(256), 0, st, img, y, N, H, W);
   return shdr::check_launch("lin_frontend");
 }

@@ -73,28 +73,34 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
 // tf.image.resize(2x, BILINEAR), half-pixel centres (dequantization_net.py:25):
 // src = (dst+0.5)/2 - 0.5 -> even dst: taps (m-1, m) lerp .75; odd dst: (m, m+1) lerp .25,
 // indices clamped; value = top + (bot - top)*ly with top = l + (r - l)*lx.
+// One thread owns one INPUT pixel quad and writes its 2x2 output quads from the 3x3 input
+// neighbourhood (9 loads per 4 stores instead of 16).
 __global__ __launch_bounds__(256) void resize2x_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        int N, int H, int W, int C) {
-  const int Ho = 2 * H, Wo = 2 * W, Q = C >> 2;
-  const long total = (long)N * Ho * Wo * Q;
+  const int Q = C >> 2;
+  const long total = (long)N * H * W * Q;
+  const long orow = (long)2 * W * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n)
-    const int hy = oh >> 1, wx = ow >> 1;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    if (oh & 1) { y0 = hy; y1 = min(hy + 1, H - 1); ly = 0.25f; }
-    else        { y0 = max(hy - 1, 0); y1 = hy; ly = 0.75f; }
-    if (ow & 1) { x0 = wx; x1 = min(wx + 1, W - 1); lx = 0.25f; }
-    else        { x0 = max(wx - 1, 0); x1 = wx; lx = 0.75f; }
+    SHDR_DECODE_QUAD(e, Q, W, H, q, w, h, n)
+    const int hm = max(h - 1, 0), hp = min(h + 1, H - 1), wm = max(w - 1, 0), wp = min(w + 1, W - 1);
     const float* b = x + (n * H * (long)W) * C + 4 * q;
-    const float4 tl = ld4(b + ((long)y0 * W + x0) * C), tr = ld4(b + ((long)y0 * W + x1) * C);
-    const float4 bl = ld4(b + ((long)y1 * W + x0) * C), br = ld4(b + ((long)y1 * W + x1) * C);
-    auto lerp2 = [&](float a, float bb, float c, float d) {
-      const float top = a + (bb - a) * lx, bot = c + (d - c) * lx;
-      return top + (bot - top) * ly;
+    const int rows[3] = {hm, h, hp};
+    float4 lo[3], hi[3];   // horizontally interpolated: lo = output column 2w, hi = output column 2w+1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* rp = b + (long)rows[r] * W * C;
+      const float4 l = ld4(rp + (long)wm * C), c = ld4(rp + (long)w * C), rr = ld4(rp + (long)wp * C);
+      lo[r] = make_float4(l.x + (c.x - l.x) * 0.75f, l.y + (c.y - l.y) * 0.75f, l.z + (c.z - l.z) * 0.75f, l.w + (c.w - l.w) * 0.75f);
+      hi[r] = make_float4(c.x + (rr.x - c.x) * 0.25f, c.y + (rr.y - c.y) * 0.25f, c.z + (rr.z - c.z) * 0.25f, c.w + (rr.w - c.w) * 0.25f);
+    }
+    auto vl = [](float4 t, float4 u, float ly) {
+      return make_float4(t.x + (u.x - t.x) * ly, t.y + (u.y - t.y) * ly, t.z + (u.z - t.z) * ly, t.w + (u.w - t.w) * ly);
     };
-    st4(y + e * 4, make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
-                               lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w)));
+    float* o = y + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * C + 4 * q;
+    st4(o, vl(lo[0], lo[1], 0.75f));
+    st4(o + C, vl(hi[0], hi[1], 0.75f));
+    st4(o + orow, vl(lo[1], lo[2], 0.25f));
+    st4(o + orow + C, vl(hi[1], hi[2], 0.25f));
   }
 }
 
@@ -161,7 +167,7 @@ extern "C" int shdr_maxpool3s2_fwd_f32(const float* x, float* y, int N, int H, i
 
 extern "C" int shdr_resize2x_fwd_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   if (int rc = check_nhwc4("resize2x", x, y, N, H, W, C)) return rc;
-  const long total = (long)N * H * 2 * W * 2 * (C / 4);
+  const long total = (long)N * H * W * (C / 4);
   hipLaunchKernelGGL(resize2x_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C);
   return shdr::check_launch("resize2x");
