@@ -227,6 +227,24 @@ int shdr_vgg_preprocess_bwd_f32(const float* dy, float* dx, int64_t npix, int in
 int shdr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
 
+/* ---- chained fine-tuning step (finetune_real_dataset.py:144-183) ---- */
+/* dimg[N,H,W,3] = J^T dF of the front end (identity + REFLECT sobel + soft-histogram slopes). */
+int shdr_lin_frontend_bwd_f32(const float* img, const float* dF, float* dimg, int N, int H, int W,
+                              int y_channels, void* stream);
+/* A = B + alpha(B)*reverse3(hal): gradients w.r.t. B (through the alpha mask too) and hal. */
+int shdr_alpha_blend_full_bwd_f32(const float* b, const float* hal, const float* dA, float* dB,
+                                  float* dhal, int64_t npix, float thr, void* stream);
+/* o_s[p][0..2] = y[p][3s..3s+2], s < nout (backward of pack3; slice of the Refinement-Net input). */
+int shdr_unpack3_f32(const float* y, float* o0, float* o1, float* o2, float* o3, int nout,
+                     int channels, int64_t npix, void* stream);
+/* out[b] = sum_i a[b][i] * (b ? b[b][i] : 1). */
+int shdr_sample_dot_f32(const float* a, const float* b, float* out, int B, int64_t n_per_sample, void* stream);
+/* out = r / (eps + sum[b]/n) * target and its gradient (finetune_real_dataset.py:170). */
+int shdr_mean_norm_fwd_f32(const float* r, const float* sum, float* out, int B, int64_t n_per_sample,
+                           float eps, float target, void* stream);
+int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, float* dr, int B,
+                           int64_t n_per_sample, float eps, float target, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,3 +331,17 @@ def joint_losses(params, vgg_params, batch, invcrf_gt, table, thr=0.12):
     loss_hal = (l1 + 0.001 * perc + 0.1 * tv) * mask
     return dict(loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal, crf_loss=crf_loss,
                 total=loss_deq + loss_lin + loss_hal, C_pred=c_pred, B_pred=b_pred, A_pred=a_pred)
+
+
+def finetune_forward(params, ldr, hdr, table, thr=0.12):
+    """finetune_real_dataset.py:144-172 (chained, training-mode BN; `_hal(pred)` read as `_hal(B_pred)`).
+    Returns the un-reduced loss tensor and the intermediates."""
+    c_pred = np.clip(deq_forward(params["deq"], ldr), 0, 1)
+    invcrf = lin_forward(params["lin"], c_pred, table, training=True)
+    b_pred = ops.apply_rf(c_pred, invcrf)
+    hal = hal_forward(params["hal"], b_pred, training=True)
+    a_pred = ops.alpha_blend(b_pred, hal, thr)
+    r = ref_forward(params["ref"], np.concatenate([a_pred, b_pred, c_pred], axis=-1))
+    r = r / (1e-6 + r.mean(axis=(1, 2, 3), keepdims=True)) * 0.5
+    loss = np.abs(ops.log_compress(r) - ops.log_compress(hdr))
+    return dict(loss=loss, C_pred=c_pred, B_pred=b_pred, A_pred=a_pred, refinement_output=r)

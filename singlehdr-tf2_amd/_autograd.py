@@ -42,8 +42,16 @@ def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
         return K.conv2d(dz, wt, cout_valid=c_count)
     if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
         return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=c_count), x_shape)
-    raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built "
-                              "(on the hot path only first layers are strided, and they take data)" % (kh, kw, stride))
+    if stride == 2:
+        # general stride 2 (the 7x7/2 first conv of the Linearization-Net in the fine-tuning chain):
+        # zero-insert dz to the input grid, then a stride-1 conv with the flipped filter and the
+        # transposed padding k-1-pad (the forward SAME pad is asymmetric: 2 before / 3 after)
+        n, h, wd, _ = x_shape
+        ho, pt = K.same_pad(h, kh, 2)
+        wo, pl = K.same_pad(wd, kw, 2)
+        up = K.upsample_zero2(dz, (n, 2 * ho, 2 * wo, dz.shape[3]))
+        return K.conv2d(up, wt, cout_valid=c_count, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(h, wd))
+    raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built" % (kh, kw, stride))
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -317,6 +325,94 @@ class BlendConstFn(torch.autograd.Function):
 
 def blend_const(base, alpha, hal_bgr, thr):
     return BlendConstFn.apply(base, alpha, hal_bgr, thr)
+
+
+# ---------------------------------------------------------------------------
+# fine-tuning chain (finetune_real_dataset.py:144-183)
+# ---------------------------------------------------------------------------
+class LinFrontendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, channels):
+        ctx.save_for_backward(img)
+        return K.lin_frontend(img, channels)
+
+    @staticmethod
+    def backward(ctx, dF):
+        (img,) = ctx.saved_tensors
+        return K.lin_frontend_bwd(img, _c(dF)), None
+
+
+def lin_frontend(img, channels):
+    return LinFrontendFn.apply(img, channels)
+
+
+class AlphaBlendFn(torch.autograd.Function):
+    """A = B + alpha(B) * reverse3(hal), gradients through B, the alpha mask and hal"""
+
+    @staticmethod
+    def forward(ctx, b_pred, hal_bgr, thr):
+        ctx.save_for_backward(b_pred, hal_bgr)
+        ctx.thr = thr
+        return K.alpha_blend(b_pred, hal_bgr, thr)
+
+    @staticmethod
+    def backward(ctx, dA):
+        b_pred, hal_bgr = ctx.saved_tensors
+        dB, dhal = K.alpha_blend_full_bwd(b_pred, hal_bgr, _c(dA), ctx.thr)
+        return dB, dhal, None
+
+
+def alpha_blend(b_pred, hal_bgr, thr):
+    return AlphaBlendFn.apply(b_pred, hal_bgr, thr)
+
+
+class Pack3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out_channels, *srcs):
+        ctx.n = len(srcs)
+        return K.pack3(list(srcs), out_channels)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (None,) + tuple(K.unpack3(_c(dy), ctx.n))
+
+
+def pack3(srcs, out_channels):
+    return Pack3Fn.apply(out_channels, *srcs)
+
+
+class Unpack3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, nout):
+        ctx.channels = y.shape[-1]
+        return K.unpack3(y, nout)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return K.pack3([_c(g) for g in grads], ctx.channels), None
+
+
+def unpack3(y, nout):
+    return Unpack3Fn.apply(y, nout)
+
+
+class MeanNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, eps, target):
+        ssum = K.sample_dot(r)
+        ctx.save_for_backward(r, ssum)
+        ctx.meta = (eps, target)
+        return K.mean_norm_fwd(r, ssum, eps, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        r, ssum = ctx.saved_tensors
+        g = _c(g)
+        return K.mean_norm_bwd(g, ssum, K.sample_dot(g, r), *ctx.meta), None, None
+
+
+def mean_norm(r, eps, target):
+    return MeanNormFn.apply(r, eps, target)
 
 
 import sys  # noqa: E402

@@ -77,6 +77,12 @@ SIGNATURES = {
     "shdr_alpha_mask_f32": (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     "shdr_alpha_blend_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     "shdr_vgg_preprocess_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_lin_frontend_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_alpha_blend_full_bwd_f32": (c_int, [c_ptr] * 5 + [c_i64, c_f32, c_ptr]),
+    "shdr_unpack3_f32": (c_int, [c_ptr] * 5 + [c_int, c_int, c_i64, c_ptr]),
+    "shdr_sample_dot_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr]),
+    "shdr_mean_norm_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f32, c_ptr]),
+    "shdr_mean_norm_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f32, c_ptr]),
     "shdr_adam_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
 }
 

@@ -60,13 +60,15 @@ def _d(t):
 
 
 def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scale=None,
-           shift=None, residual=None, act2=ACT_NONE, algo=ALGO_AUTO, out=None, cout_valid=None):
+           shift=None, residual=None, act2=ACT_NONE, algo=ALGO_AUTO, out=None, cout_valid=None,
+           pad=None, out_hw=None):
     """y = act2(affine(act1(conv(concat[x, x2_scale*x2], w) + bias)) + residual), SAME padding.
 
     `cout_valid` < w.shape[3] says the filter is zero-padded along Cout (to a multiple of 16 so
-    that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored."""
+    that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored.
+    `pad=(top, left)` / `out_hw=(Ho, Wo)` override the SAME rule (used by the strided dgrad)."""
     fused = scale is not None or shift is not None or residual is not None or act2 != ACT_NONE
-    if not fused and _needs_grad(x, x2, w, bias):     # fused epilogues are the inference path: never taped
+    if not fused and pad is None and _needs_grad(x, x2, w, bias):   # fused epilogues are the inference path: never taped
         return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
                                shift=shift, residual=residual, act2=act2, algo=algo, cout_valid=cout_valid)
     lib = _lib.load()
@@ -85,6 +87,10 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
         raise ValueError("conv2d: filter expects %d input channels, got %d+%d" % (cin, c1, c2))
     ho, pt = same_pad(h, kh, stride)
     wo, pl = same_pad(wd, kw, stride)
+    if pad is not None:
+        pt, pl = pad
+    if out_hw is not None:
+        ho, wo = out_hw
     d = _lib.ConvDesc()
     d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
     d.Cout, d.KH, d.KW, d.stride = cout_gemm, kh, kw, stride
@@ -179,6 +185,8 @@ def soft_hist(img, max_bin):
 
 
 def lin_frontend(img, channels=96):
+    if _needs_grad(img):
+        return AUTOGRAD.lin_frontend(img, channels)
     lib = _lib.load()
     img = _chk(_d(img), "img")
     n, h, w, c = img.shape
@@ -284,7 +292,9 @@ def reverse3(x):
 
 def alpha_blend(b_pred, hal_bgr, thr=0.12, return_alpha=False):
     if _needs_grad(b_pred, hal_bgr):
-        raise NotImplementedError("alpha_blend: use alpha_mask() + blend_const() on the training path")
+        if return_alpha:
+            raise NotImplementedError("alpha_blend: return_alpha is not available on the taped path")
+        return AUTOGRAD.alpha_blend(b_pred, hal_bgr, thr)
     lib = _lib.load()
     b_pred, npix = _pix3(b_pred, "b_pred")
     hal_bgr, npix2 = _pix3(hal_bgr, "hal_bgr")
@@ -298,6 +308,8 @@ def alpha_blend(b_pred, hal_bgr, thr=0.12, return_alpha=False):
 
 
 def pack3(srcs, out_channels=None):
+    if _needs_grad(*srcs):
+        return AUTOGRAD.pack3(list(srcs), out_channels)
     lib = _lib.load()
     srcs = [_pix3(s, "src%d" % i)[0] for i, s in enumerate(srcs)]
     n = len(srcs)
@@ -634,3 +646,73 @@ def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0
         _chk(_d(t), nm)
     _lib.check(lib.shdr_adam_f32(_ptr(_d(p)), _ptr(_d(g)), _ptr(m), _ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
                                  float(eps), float(grad_scale), _stream()), "shdr_adam_f32")
+
+
+def lin_frontend_bwd(img, dF):
+    lib = _lib.load()
+    img, dF = _chk(_d(img), "img"), _chk(_d(dF), "dF")
+    n, h, w, _ = img.shape
+    dimg = torch.empty_like(img)
+    _lib.check(lib.shdr_lin_frontend_bwd_f32(_ptr(img), _ptr(dF), _ptr(dimg), n, h, w, dF.shape[3], _stream()), "shdr_lin_frontend_bwd_f32")
+    return dimg
+
+
+def alpha_blend_full_bwd(b_pred, hal_bgr, dA, thr):
+    lib = _lib.load()
+    b_pred, npix = _pix3(b_pred, "b_pred")
+    hal_bgr, dA = _chk(_d(hal_bgr), "hal"), _chk(_d(dA), "dA")
+    dB, dhal = torch.empty_like(b_pred), torch.empty_like(b_pred)
+    _lib.check(lib.shdr_alpha_blend_full_bwd_f32(_ptr(b_pred), _ptr(hal_bgr), _ptr(dA), _ptr(dB), _ptr(dhal), npix, float(thr),
+                                                 _stream()), "shdr_alpha_blend_full_bwd_f32")
+    return dB, dhal
+
+
+def unpack3(y, nout):
+    """the first `nout` 3-channel slices of y [..., C]: (y[..., 0:3], y[..., 3:6], ...)"""
+    if _needs_grad(y):
+        return AUTOGRAD.unpack3(y, nout)
+    lib = _lib.load()
+    y = _chk(_d(y), "y")
+    c = y.shape[-1]
+    npix = y.numel() // c
+    outs = [torch.empty(tuple(y.shape[:-1]) + (3,), device=y.device, dtype=torch.float32) for _ in range(nout)]
+    p = [_ptr(o) for o in outs] + [None] * (4 - nout)
+    _lib.check(lib.shdr_unpack3_f32(_ptr(y), p[0], p[1], p[2], p[3], nout, c, npix, _stream()), "shdr_unpack3_f32")
+    return tuple(outs)
+
+
+def sample_dot(a, b=None):
+    lib = _lib.load()
+    a = _chk(_d(a), "a")
+    bs = a.shape[0]
+    out = torch.empty(bs, device=a.device, dtype=torch.float32)
+    _lib.check(lib.shdr_sample_dot_f32(_ptr(a), _ptr(None if b is None else _chk(_d(b), "b")), _ptr(out), bs, a.numel() // bs, _stream()),
+               "shdr_sample_dot_f32")
+    return out
+
+
+def mean_norm(r, eps=1e-6, target=0.5):
+    """r / (eps + mean over (1,2,3) of r) * target   (finetune_real_dataset.py:170)"""
+    if _needs_grad(r):
+        return AUTOGRAD.mean_norm(r, eps, target)
+    return mean_norm_fwd(r, sample_dot(r), eps, target)
+
+
+def mean_norm_fwd(r, ssum, eps, target):
+    lib = _lib.load()
+    r = _chk(_d(r), "r")
+    bs = r.shape[0]
+    out = torch.empty_like(r)
+    _lib.check(lib.shdr_mean_norm_fwd_f32(_ptr(r), _ptr(ssum), _ptr(out), bs, r.numel() // bs, float(eps), float(target), _stream()),
+               "shdr_mean_norm_fwd_f32")
+    return out
+
+
+def mean_norm_bwd(g, ssum, gdot, eps, target):
+    lib = _lib.load()
+    g = _chk(_d(g), "g")
+    bs = g.shape[0]
+    dr = torch.empty_like(g)
+    _lib.check(lib.shdr_mean_norm_bwd_f32(_ptr(g), _ptr(ssum), _ptr(gdot), _ptr(dr), bs, g.numel() // bs, float(eps), float(target),
+                                          _stream()), "shdr_mean_norm_bwd_f32")
+    return dr

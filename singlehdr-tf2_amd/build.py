@@ -22,6 +22,7 @@ SOURCES = {
     "conv.hip": [],
     "wgrad.hip": [],
     "bwd.hip": [],
+    "finetune.hip": [],
     "frontend.hip": ["-ffp-contract=off"],
     "pool.hip": [],
     "crf.hip": [],

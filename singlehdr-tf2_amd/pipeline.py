@@ -165,3 +165,46 @@ class JointTrainStep:
         if apply:
             self.optimizer.step()
         return out
+
+
+class FinetuneStep:
+    """The chained `train_step(ldr, hdr)` of finetune_real_dataset.py:144-183 (with the reference's
+    `_hal(pred, ...)` typo read as `_hal(B_pred, ...)`): deq -> clip -> lin -> apply_rf
+    -> alpha -> hal -> blend -> ref -> mean-normalise -> log-compress -> |.|, the UN-reduced loss is
+    differentiated (= gradient of its sum), Adam 1e-5 on the variables of all four nets."""
+
+    LEARNING_RATE = 1e-5   # finetune_real_dataset.py:24
+    THRESHOLD = 0.12       # finetune_real_dataset.py:26
+
+    def __init__(self, deq, lin, hal, ref, lr=None, process_group=None, world_size=1):
+        self._deq, self._lin, self._hal, self._ref = deq, lin, hal, ref
+        self.params = FlatParams([deq, lin, hal, ref])
+        self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
+        self.pg, self.world = process_group, world_size
+
+    def forward(self, ldr, hdr):
+        pred_deq = self._deq(ldr, training=True)
+        C_pred = K.clip(pred_deq, 0.0, 1.0)
+        pred_invcrf = self._lin(C_pred, training=True)
+        B_pred = tf_utils.apply_rf(C_pred, pred_invcrf)
+        bgr_hal_res = self._hal(B_pred, training=True)
+        A_pred = K.alpha_blend(B_pred, bgr_hal_res, self.THRESHOLD)      # alpha is a function of B_pred here
+        with torch.no_grad():
+            hdr_gamma = K.logc(hdr)
+        refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 12), training=True)
+        refinement_output = K.mean_norm(refinement_output, 1e-6, 0.5)
+        refinement_output_gamma = K.logc(refinement_output)
+        n_per = refinement_output_gamma[0].numel()
+        loss_sum = K.diff_loss(refinement_output_gamma, hdr_gamma, 1) * float(n_per)   # per-sample SUM of |.|
+        return dict(loss_sum=loss_sum, C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, refinement_output=refinement_output)
+
+    def __call__(self, ldr, hdr, apply=True):
+        self.params.zero_grad()
+        out = self.forward(ldr, hdr)
+        out["loss_sum"].sum().backward()
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        if apply:
+            self.optimizer.step()
+        return out

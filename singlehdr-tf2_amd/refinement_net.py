@@ -23,8 +23,8 @@ class model(_unet):
 
     def call(self, input_images, training="training"):
         x = self._trunk(input_images)
-        if x.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("Refinement-Net backward (finetune_real_dataset.py:144-183) is not built yet: "
-                                      "call under torch.no_grad()")
+        if x.requires_grad and torch.is_grad_enabled():   # taped: slice + residual join as separate ops
+            (first3,) = K.unpack3(input_images, 1)
+            return K.AUTOGRAD.add_relu(first3, self.out.call_padded(x, cout_pad=16))
         # relu(input[..., 0:3] + out(x))  (refinement_net.py:63-66): residual read with channel stride 9
         return self.out.call_padded(x, cout_pad=16, residual=input_images, act2=K.ACT_RELU)

@@ -45,8 +45,8 @@ def test_refinement_net_parity(shdr):
         assert rel_err(host(m(dev(x), training=False)), ref) <= TOL                  # 9-channel input (reference surface)
         x12 = np.concatenate([x, np.zeros((1, 64, 64, 3))], -1)
         assert rel_err(host(m(dev(x12), training=False)), ref) <= TOL                # zero-padded fast path
-    with pytest.raises(NotImplementedError):
-        m(dev(x), training=True)                                                     # backward of ref: next round
+    y = m(dev(x12), training=True)                                                   # taped path (fine-tuning chain)
+    assert y.requires_grad and rel_err(host(y), ref) <= TOL
 
 
 def test_hallucination_net_parity(shdr):

@@ -112,9 +112,25 @@ def apply_rf(x, rf):
     return out.reshape(x.shape)
 
 
+def lin_frontend(img):
+    """differentiable restatement of oracle.ops.lin_frontend (sobel REFLECT + soft histograms)"""
+    n, h, w, c = img.shape
+    xp = F.pad(_nchw(img), (1, 1, 1, 1), mode="reflect")
+    ky = torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]], dtype=DT)
+    kern = torch.stack([ky, ky.T])[:, None]                      # [2,1,3,3]: dy, dx
+    e = F.conv2d(xp.reshape(n * c, 1, h + 2, w + 2), kern).reshape(n, c, 2, h, w)
+    edges = e.permute(0, 3, 4, 1, 2).reshape(n, h, w, 2 * c)    # channel = c*2 + {dy, dx}
+    feats = [img, edges]
+    for B in (4, 8, 16):
+        for i in range(1, B + 1):
+            d = (img - (2.0 * i - 1.0) / (2.0 * B)).abs()
+            feats.append(torch.where(d < 1.0 / B, 1.0 - d * B, torch.zeros_like(d)))
+    return torch.cat(feats, -1)
+
+
 def lin_forward(p, img, table, training):
     q = "crf_feature_net."
-    feat_in = T(nops.lin_frontend(img.detach().numpy()))
+    feat_in = lin_frontend(img) if img.requires_grad else T(nops.lin_frontend(img.detach().numpy()))
 
     def res1(n, t, s):
         n1 = bn(p, n + ".norm1", _c(p, n + ".conv1", t, s), training)
@@ -218,3 +234,38 @@ def joint_losses(params, vgg_params, batch, invcrf_gt, table, thr=0.12):
     loss_hal = (l1 + 0.001 * perc + 0.1 * tv_loss(ya)) * m
     return dict(total=loss_deq + loss_lin + loss_hal, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
                 crf_loss=crf_loss, C_pred=c_pred, B_pred=b_pred, A_pred=a_pred)
+
+
+def ref_forward(p, x):
+    def down(n, t):
+        t = avg_pool2(t)
+        return lrelu(_c(p, n + ".conv2", lrelu(_c(p, n + ".conv1", t))))
+
+    def up(n, t, skip):
+        t = lrelu(_c(p, n + ".conv1", resize2x(t)))
+        return lrelu(_c(p, n + ".conv2", torch.cat([t, skip], -1)))
+
+    t = lrelu(_c(p, "conv1", x))
+    s1 = lrelu(_c(p, "conv2", t))
+    s2 = down("d2", s1)
+    s3 = down("d3", s2)
+    s4 = down("d4", s3)
+    t = down("enc", s4)
+    t = up("u4", t, s4)
+    t = up("u3", t, s3)
+    t = up("u2", t, s2)
+    t = up("u1", t, s1)
+    return torch.relu(x[..., 0:3] + _c(p, "out", t))
+
+
+def finetune_forward(params, ldr, hdr, table, thr=0.12):
+    """finetune_real_dataset.py:144-172 in float64 with autograd."""
+    c_pred = torch.clamp(deq_forward(params["deq"], ldr), 0, 1)
+    invcrf = lin_forward(params["lin"], c_pred, table, True)
+    b_pred = apply_rf(c_pred, invcrf)
+    hal = hal_forward(params["hal"], b_pred, True)
+    a_pred = b_pred + alpha_mask(b_pred, thr) * hal.flip(-1)
+    r = ref_forward(params["ref"], torch.cat([a_pred, b_pred, c_pred], -1))
+    r = r / (1e-6 + r.mean(dim=(1, 2, 3), keepdim=True)) * 0.5
+    loss = (logc(r) - logc(hdr)).abs()
+    return dict(loss=loss, C_pred=c_pred, B_pred=b_pred, A_pred=a_pred, refinement_output=r)
