@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one HIP graph (small-batch latency)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed joint-training steps (0 = skip that leg)")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-size", type=int, default=256)
@@ -104,7 +105,8 @@ def main():
     hal = pkg.hallucination_net.model()
     for m in (deq, lin, hal):
         randomise_bn(m, gen)
-    run = pkg.pipeline.Inference(deq, lin, hal, None)
+    run = (pkg.pipeline.GraphedInference if args.graph else pkg.pipeline.Inference)(deq, lin, hal, None)
+    eager = pkg.pipeline.Inference(deq, lin, hal, None)
 
     g = torch.Generator().manual_seed(3 + rank)
     ldr = (torch.round(torch.rand((args.batch, args.size, args.size, 3), generator=g) * 255.0) / 255.0).cuda()
@@ -160,7 +162,7 @@ def main():
         K.conv2d = timed_conv
         try:
             for _ in range(reps):
-                run(ldr)
+                eager(ldr)
             torch.cuda.synchronize()
         finally:
             K.conv2d = orig

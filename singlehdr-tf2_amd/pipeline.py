@@ -49,6 +49,38 @@ class Inference:
 # ---------------------------------------------------------------------------
 # joint training step (joint_training.py:137-194)
 # ---------------------------------------------------------------------------
+class GraphedInference:
+    """`Inference` captured once into a HIP graph (hipGraph via torch.cuda.CUDAGraph) and replayed: the
+    ~100 kernel launches of one forward become ONE graph launch, which removes the launch gaps that
+    dominate small-batch latency (the reference's tool runs one image at a time,
+    test_real_refinement.py:119-155).  Shapes are static: one graph per input shape, kept in a cache."""
+
+    def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD):
+        self._eager = Inference(deq, lin, hal, ref, threshold)
+        self._graphs = {}
+
+    def __call__(self, ldr):
+        key = tuple(ldr.shape)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = torch.empty_like(ldr)
+            static_in.copy_(ldr)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):             # warm-up off the capture: kernel attributes, caches
+                for _ in range(2):
+                    self._eager(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._eager(static_in)
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(ldr)
+        graph.replay()
+        return static_out
+
+
 class FlatParams:
     """All trainable variables of several models as views of ONE flat fp32 buffer (plus flat grad / Adam
     moment buffers): one Adam kernel and one RCCL all-reduce per step instead of one per variable."""

@@ -103,3 +103,14 @@ def test_inference_batch_independence_256(shdr):
     single = host(run(x[1:2].contiguous()))
     np.testing.assert_array_equal(full[1:2], single)
     assert np.isfinite(full).all() and (full >= 0).all()
+
+
+def test_graphed_inference_equals_eager(shdr):
+    """the HIP-graph replay runs the same kernels on the same data: bit-identical, also after new input"""
+    ms = {k: build(shdr, k, 40 + i)[0] for i, k in enumerate(("deq", "lin", "hal", "ref"))}
+    eager = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    graphed = shdr.pipeline.GraphedInference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        x = dev(quantised_image(rng, (1, 128, 96, 3)))
+        np.testing.assert_array_equal(host(graphed(x)), host(eager(x)))
