@@ -145,17 +145,27 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
     if rank == 0 and not args.no_roofline:
-        records = []
+        records = []     # (kernel label, flops, e0, e1, description, nested)
         orig = K.conv2d
+        depth = [0]
 
         def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            wino = (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+                    and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}
+                    and K.winograd_pays(w.shape[2], w.shape[3]))
             e0.record()
-            y = orig(x, w, bias, stride=stride, x2=x2, **kw)
+            depth[0] += 1
+            try:
+                y = orig(x, w, bias, stride=stride, x2=x2, **kw)
+            finally:
+                depth[0] -= 1
             e1.record()
-            records.append((conv_variant(w, x, x2, kw.get("algo", 0)), conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
+            label = "winograd_f2x2_3x3 (transforms + batched GEMM)" if wino else conv_variant(w, x, x2, kw.get("algo", 0))
+            records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
                             "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
-                                                        0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride)))
+                                                        0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),
+                            depth[0] > 0))
             return y
 
         reps = 3
@@ -166,21 +176,27 @@ def main():
             torch.cuda.synchronize()
         finally:
             K.conv2d = orig
-        agg = {}
         if args.layers:
-            for var, fl, e0, e1, desc in records[:len(records) // reps]:
+            for var, fl, e0, e1, desc, nested in records[:len(records) // reps]:
                 ms = e0.elapsed_time(e1)
-                print("%-28s %-28s %8.3f ms %7.2f TF" % (var, desc, ms, fl / ms / 1e9), file=sys.stderr)
-        for var, fl, e0, e1, _ in records:
-            a = agg.setdefault(var, [0.0, 0.0, 0])
-            a[0] += fl
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += 1
+                print("%-46s %-28s %8.3f ms %7.2f TF%s" % (var, desc, ms, fl / ms / 1e9, "  (nested GEMM, executed FLOPs)" if nested else ""),
+                      file=sys.stderr)
+        # layers: top-level calls with the reference layer's algorithmic FLOPs; kernels: every launch of a conv
+        # kernel (top-level direct convs + the GEMMs nested in Winograd layers, with the FLOPs they execute)
+        layers, agg = {}, {}
+        for var, fl, e0, e1, _, nested in records:
+            sec = e0.elapsed_time(e1) * 1e-3
+            if not nested:
+                a = layers.setdefault(var, [0.0, 0.0, 0])
+                a[0] += fl; a[1] += sec; a[2] += 1
+            if nested or not var.startswith("winograd"):
+                a = agg.setdefault(var, [0.0, 0.0, 0])
+                a[0] += fl; a[1] += sec; a[2] += 1
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[dom]
         achieved = fl / sec / 1e12
-        conv_total_flops = sum(a[0] for a in agg.values()) / reps
-        conv_total_sec = sum(a[1] for a in agg.values()) / reps
+        conv_total_flops = sum(a[0] for a in layers.values()) / reps
+        conv_total_sec = sum(a[1] for a in layers.values()) / reps
         # HBM bytes per launch of the dominant kernel: PMC counters collected offline (rocprofv3 cannot profile
         # the process it runs in) with the same workload -- see profiles/r01_traffic.json for the recipe
         traffic = None
@@ -203,6 +219,8 @@ def main():
                          "gflop_per_step": round(conv_total_flops / 1e9, 1)},
             "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
                                "launches_per_step": v[2] // reps} for k, v in sorted(agg.items())},
+            "per_layer_path": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
+                                   "layers_per_step": v[2] // reps} for k, v in sorted(layers.items())},
         }
 
     # ---- CPU baseline: the float32 NumPy oracle ("port") on a bounded sample, rank 0, N=1 only ------

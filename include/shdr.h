@@ -83,6 +83,9 @@ typedef struct shdr_conv2d_desc {
   int32_t cout_valid;       /* channels stored to y (0 -> Cout).  Cout may be a  */
                             /* zero-padded filter width (multiple of 16) so that */
                             /* e.g. a 3-channel head runs on the MFMA tile       */
+  int64_t w_batch_stride;   /* filter elements between consecutive images; 0 =   */
+                            /* one filter for the whole batch.  Used by the      */
+                            /* Winograd path: 16 GEMMs with 16 filters, 1 launch */
 } shdr_conv2d_desc;
 
 int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
@@ -226,6 +229,20 @@ int shdr_vgg_preprocess_bwd_f32(const float* dy, float* dx, int64_t npix, int in
  * p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
 int shdr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- Winograd F(2x2,3x3) for wide 3x3 stride-1 SAME convs (hallucination_net.py:47-48,63-65,81,121;
+ *      vgg16.py:33): y = output_transform( V[xi] @ U[xi] ),  xi = 0..15.  The 16 GEMMs are ONE call of
+ *      shdr_conv2d_fwd_f32 with N=16, H=rows/16, W=16, 1x1, w_batch_stride = Cin*Cout. ---- */
+/* u[16][Cin][Cout] = G g G^T of the HWIO 3x3 filter w. */
+int shdr_winograd_filter_f32(const float* w, float* u, int Cin, int Cout, void* stream);
+/* rows of each V / M plane: N*ceil(H/2)*ceil(W/2) rounded up to 128. */
+int64_t shdr_winograd_tiles(int N, int H, int W);
+/* v[16][rows][C] = B^T d B of the 4x4 patches of x [N,H,W,C] (zero padded). */
+int shdr_winograd_input_f32(const float* x, float* v, int N, int H, int W, int C, void* stream);
+/* y [N,H,W,C] = act2(affine(act1(A^T m A + bias))), m [16][rows][C]. */
+int shdr_winograd_output_f32(const float* m, float* y, const float* bias, const float* scale,
+                             const float* shift, int N, int H, int W, int C, int act1, int act2,
+                             void* stream);
 
 /* ---- chained fine-tuning step (finetune_real_dataset.py:144-183) ---- */
 /* dimg[N,H,W,3] = J^T dF of the front end (identity + REFLECT sobel + soft-histogram slopes). */

@@ -25,7 +25,8 @@ class ConvDesc(ctypes.Structure):
                 ("x2_scale", ctypes.c_float),
                 ("act1", ctypes.c_int32), ("act2", ctypes.c_int32),
                 ("res_cstride", ctypes.c_int32), ("y_cstride", ctypes.c_int32),
-                ("algo", ctypes.c_int32), ("cout_valid", ctypes.c_int32)]
+                ("algo", ctypes.c_int32), ("cout_valid", ctypes.c_int32),
+                ("w_batch_stride", ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/shdr.h
@@ -77,6 +78,10 @@ SIGNATURES = {
     "shdr_alpha_mask_f32": (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     "shdr_alpha_blend_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     "shdr_vgg_preprocess_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_winograd_filter_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    "shdr_winograd_tiles": (c_i64, [c_int, c_int, c_int]),
+    "shdr_winograd_input_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_winograd_output_f32": (c_int, [c_ptr] * 5 + [c_int, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_lin_frontend_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_alpha_blend_full_bwd_f32": (c_int, [c_ptr] * 5 + [c_i64, c_f32, c_ptr]),
     "shdr_unpack3_f32": (c_int, [c_ptr] * 5 + [c_int, c_int, c_i64, c_ptr]),

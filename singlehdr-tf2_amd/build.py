@@ -23,6 +23,7 @@ SOURCES = {
     "wgrad.hip": [],
     "bwd.hip": [],
     "finetune.hip": [],
+    "winograd.hip": [],
     "frontend.hip": ["-ffp-contract=off"],
     "pool.hip": [],
     "crf.hip": [],

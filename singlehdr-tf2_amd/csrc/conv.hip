@@ -43,6 +43,7 @@ struct ConvArgs {
   int nblk_m, nblk_n;
   float x2_scale;
   int act1, act2, res_cs, y_cs;
+  long w_bstride;  // filter elements between consecutive images (0: one filter for the batch)
   int no_dma;      // force the register-staged kernel (SHDR_ALGO_MFMA_REG)
   int cout_valid;  // channels actually stored (<= Cout; the filter may be zero-padded to Cout)
 };
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     for (int i = 0; i < BPASS; ++i) {
       const int bk = bk0 + BROWS_PER_PASS * i;
       bok[i] = (BFULL || bk < BK) && (FAST || (int)krow0 + bk < a.K);
-      breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)(bok[i] ? wbase + wrow[i] : 0u));
+      breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)img * a.w_bstride + (size_t)(bok[i] ? wbase + wrow[i] : 0u));
     }
   };
 
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
   const int n0 = pn * BN;
   const int oh0 = ty * TH, ow0 = tx * 16;
   const float* zero = g_zero_page;
+  const float* wimg = a.w + (size_t)img * a.w_bstride;
 
   // ---- A geometry: instruction i of this wave fills rows (wave*AI + i)*8 .. +7 -------------
   int ihb[AI], iwb[AI], aq[AI];
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
 #pragma unroll
       for (int j = 0; j < BI; ++j) {
         const bool ok = FAST || ((int)krow0 + wk[j] < a.K);
-        const float* p = ok ? a.w + (size_t)(wbase + woff[j]) : zero;
+        const float* p = ok ? wimg + (size_t)(wbase + woff[j]) : zero;
         __builtin_amdgcn_global_load_lds((shdr_gptr_t)p, (shdr_lptr_t)(Bb + j * 256), 16, 0, 0);
       }
     }
@@ -690,7 +692,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   SHDR_REQUIRE((long)d->N * d->H * d->W < (1L << 31) && (long)d->N * d->Ho * d->Wo < (1L << 31),
                SHDR_E_SHAPE, "conv2d: more than 2^31 pixels");
   SHDR_REQUIRE((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) < (1L << 32) &&
-                   (long)d->KH * d->KW * (d->C1 + d->C2) * d->Cout < (1L << 32),
+                   (long)d->KH * d->KW * (d->C1 + d->C2) * d->Cout < (1L << 32) && d->w_batch_stride >= 0,
                SHDR_E_SHAPE, "conv2d: tensor with more than 2^32 elements");
 
   ConvArgs a{};
@@ -706,6 +708,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   a.x2_scale = d->C2 > 0 ? d->x2_scale : 1.0f;
   a.act1 = d->act1; a.act2 = d->act2;
   a.res_cs = d->res_cstride; a.y_cs = y_cs; a.cout_valid = cout_valid;
+  a.w_bstride = d->w_batch_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   const bool ragged = (cout_valid % 4) != 0;  // scalar epilogue: no alignment demands on y/res/bias
@@ -727,6 +730,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   }
   if (algo == SHDR_ALGO_DIRECT) {
     SHDR_REQUIRE(cout_valid == a.Cout, SHDR_E_SHAPE, "conv2d: direct path does not take padded filters");
+    SHDR_REQUIRE(a.w_bstride == 0, SHDR_E_SHAPE, "conv2d: direct path does not take per-image filters");
     if (a.Cout <= 3) return launch_direct<3>(a, st);
     if (a.Cout % 16 == 0) return launch_direct<16>(a, st);
     return launch_direct<8>(a, st);

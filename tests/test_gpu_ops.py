@@ -273,3 +273,21 @@ def test_glue_ops_parity(shdr):
     p12 = host(K.pack3([dev(x), dev(b), dev(hal)], 12))
     np.testing.assert_array_equal(p12[..., :9], p)
     assert float(np.abs(p12[..., 9:]).max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 13, 18, 32, 64), (1, 8, 8, 256, 256), (3, 6, 4, 128, 16)])
+def test_conv2d_winograd_parity(shdr, shape):
+    """Winograd F(2x2,3x3) path (filter / input / output transforms + batched MFMA GEMM) vs the float64 oracle"""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    u = K.winograd_filter(dev(wt))
+    ref = oracle_conv(x, wt, b, act1=1, scale=sc, shift=sh, act2=1)
+    y = K.conv2d_winograd(dev(x), u, dev(b), act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    y0 = K.conv2d_winograd(dev(x), u)
+    assert rel_err(host(y0), oracle_conv(x, wt)) <= TOL
+    assert rel_err(host(y0), host(K.conv2d(dev(x), dev(wt)))) <= 5e-6     # vs the direct MFMA kernel
