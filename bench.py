@@ -41,10 +41,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
+    ap.add_argument("--streams", type=int, default=2, help="inference: batch slices run on this many HIP streams")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one HIP graph (small-batch latency)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed joint-training steps (0 = skip that leg)")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-size", type=int, default=256)
+    ap.add_argument("--single-stream", action="store_true", help="joint step: run deq / lin / hal on one stream")
     return ap.parse_args()
 
 
@@ -105,7 +107,8 @@ def main():
     hal = pkg.hallucination_net.model()
     for m in (deq, lin, hal):
         randomise_bn(m, gen)
-    run = (pkg.pipeline.GraphedInference if args.graph else pkg.pipeline.Inference)(deq, lin, hal, None)
+    run = (pkg.pipeline.GraphedInference(deq, lin, hal, None) if args.graph
+           else pkg.pipeline.Inference(deq, lin, hal, None, streams=args.streams))
     eager = pkg.pipeline.Inference(deq, lin, hal, None)
 
     g = torch.Generator().manual_seed(3 + rank)
@@ -140,7 +143,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full deq+lin+hal inference, batch=%d x %dx%d per GPU, "
                                "fp32 (exact-fp32 MFMA), histogram B=4/8/16" % (args.batch, args.size, args.size),
-                   "per_gpu_batch": args.batch, "parallelism": "batch-sharded x%d, no collective" % n_gpus},
+                   "per_gpu_batch": args.batch, "hip_streams_per_gpu": args.streams,
+                   "parallelism": "batch-sharded x%d, no collective" % n_gpus},
     }
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
@@ -269,7 +273,7 @@ def main():
             dd[name] = [((torch.rand((3, 3, cin, cout), generator=vg) * 2 - 1) * lim).numpy(), torch.zeros(cout).numpy()]
         vgg = pkg.vgg16.Vgg16(data_dict=dd)
         step = pkg.pipeline.JointTrainStep(deq, lin, hal, vgg, process_group=(dist.group.WORLD if dist is not None else None),
-                                           world_size=world)
+                                           world_size=world, multi_stream=not args.single_stream)
         step(ds, inv)                      # warm-up (allocator, kernel attributes, RCCL rings)
         barrier()
         t0 = time.perf_counter()

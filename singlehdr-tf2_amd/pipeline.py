@@ -20,13 +20,29 @@ THRESHOLD = 0.12  # test_real_refinement.py:28
 class Inference:
     """Callable equivalent of the reference's `inference(ldr)` tf.function."""
 
-    def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD):
+    def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD, streams=1):
         self._deq, self._lin, self._hal, self._ref = deq, lin, hal, ref
         self.threshold = threshold
+        # streams > 1: the batch is cut into that many slices, each run on its own HIP stream -- images are
+        # independent, and one slice's small / low-occupancy kernels overlap with another's large ones
+        self._streams = [torch.cuda.Stream() for _ in range(streams)] if streams > 1 else None
 
     def __call__(self, ldr, return_intermediates=False):
         with torch.no_grad():
-            return self._run(ldr, return_intermediates)
+            if self._streams is None or return_intermediates or ldr.shape[0] < len(self._streams):
+                return self._run(ldr, return_intermediates)
+            main = torch.cuda.current_stream()
+            parts = torch.chunk(ldr, len(self._streams), dim=0)
+            outs = []
+            for st, part in zip(self._streams, parts):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs.append(self._run(part.contiguous(), False))
+            for st in self._streams:
+                main.wait_stream(st)
+            for o in outs:
+                o.record_stream(main)
+            return torch.cat(outs, dim=0)
 
     def _run(self, ldr, return_intermediates):
         pred_deq = self._deq(ldr, training=False)
@@ -141,48 +157,60 @@ class JointTrainStep:
     LEARNING_RATE = 1e-5   # joint_training.py:20
     THRESHOLD = 0.12       # joint_training.py:140
 
-    def __init__(self, deq, lin, hal, vgg, vgg2=None, lr=None, process_group=None, world_size=1):
+    def __init__(self, deq, lin, hal, vgg, vgg2=None, lr=None, process_group=None, world_size=1, multi_stream=True):
         self._deq, self._lin, self._hal, self._vgg, self._vgg2 = deq, lin, hal, vgg, vgg2 or vgg
         self.params = FlatParams([deq, lin, hal])
         self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
         self.pg, self.world = process_group, world_size
+        self.multi_stream = multi_stream
+        self._streams = tuple(torch.cuda.Stream() for _ in range(3)) if multi_stream else None
 
     def losses(self, ds, invcrf):
         ldr, jpeg_img_float, clipped_hdr_t, hdr_t, loss_mask = ds
         mask = loss_mask.reshape(-1)
         thr = self.THRESHOLD
-        alpha = K.alpha_mask(clipped_hdr_t, thr)
+        # The three nets are fed ground-truth intermediates, so their forward AND backward passes are independent
+        # (SURVEY.md section 3.2): each runs on its own HIP stream (torch replays an op's backward on its forward stream), which
+        # lets the small Dequantization / Linearization kernels fill the CUs the big Hallucination kernels leave idle.
+        main = torch.cuda.current_stream()
+        streams = self._streams if self.multi_stream else (main, main, main)
+        for st in streams:
+            st.wait_stream(main)
 
-        # Dequantization (:150-153)
-        pred_deq = self._deq(jpeg_img_float, training=True)
-        C_pred = K.clip(pred_deq, 0.0, 1.0)
-        loss_deq = K.diff_loss(C_pred, ldr, 0) * mask
+        with torch.cuda.stream(streams[0]):   # Dequantization (:150-153)
+            pred_deq = self._deq(jpeg_img_float, training=True)
+            C_pred = K.clip(pred_deq, 0.0, 1.0)
+            loss_deq = K.diff_loss(C_pred, ldr, 0) * mask
 
-        # Linearization (:156-160)
-        pred_invcrf = self._lin(ldr, training=True)
-        B_pred = tf_utils.apply_rf(ldr, pred_invcrf)
-        crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
-        loss_lin = (10.0 * K.diff_loss(B_pred, clipped_hdr_t, 0) + crf_loss) * mask
+        with torch.cuda.stream(streams[1]):   # Linearization (:156-160)
+            pred_invcrf = self._lin(ldr, training=True)
+            B_pred = tf_utils.apply_rf(ldr, pred_invcrf)
+            crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
+            loss_lin = (10.0 * K.diff_loss(B_pred, clipped_hdr_t, 0) + crf_loss) * mask
 
-        # Hallucination (:163-182)
-        bgr_pred_hal = self._hal(clipped_hdr_t, training=True)
-        A_pred = K.blend_const(clipped_hdr_t, alpha, bgr_pred_hal, thr)      # clipped + alpha * bgr2rgb(hal)
-        y_final_gamma = K.logc(A_pred)
-        with torch.no_grad():
-            hdr_t_gamma = K.logc(hdr_t)
-            target_feats = self._vgg2(hdr_t_gamma)
-        feats = self._vgg(y_final_gamma)
-        perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
-        l1loss_hal = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
-        tv_loss = K.tv_loss(y_final_gamma)                                     # batch-global scalar [1]
-        tv_w = mask
-        if self.pg is not None and self.world > 1:
-            # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
-            import torch.distributed as dist
-            msum = mask.sum()
-            dist.all_reduce(msum, group=self.pg)
-            tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
-        loss_hal = (l1loss_hal + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
+        with torch.cuda.stream(streams[2]):   # Hallucination (:163-182)
+            alpha = K.alpha_mask(clipped_hdr_t, thr)
+            bgr_pred_hal = self._hal(clipped_hdr_t, training=True)
+            A_pred = K.blend_const(clipped_hdr_t, alpha, bgr_pred_hal, thr)      # clipped + alpha * bgr2rgb(hal)
+            y_final_gamma = K.logc(A_pred)
+            with torch.no_grad():
+                hdr_t_gamma = K.logc(hdr_t)
+                target_feats = self._vgg2(hdr_t_gamma)
+            feats = self._vgg(y_final_gamma)
+            perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
+            l1loss_hal = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
+            tv_loss = K.tv_loss(y_final_gamma)                                     # batch-global scalar [1]
+            tv_w = mask
+            if self.pg is not None and self.world > 1:
+                # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
+                import torch.distributed as dist
+                msum = mask.sum()
+                dist.all_reduce(msum, group=self.pg)
+                tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
+            loss_hal = (l1loss_hal + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
+
+        for st in streams:
+            main.wait_stream(st)
         total_loss = loss_deq + loss_lin + loss_hal
         return dict(total=total_loss, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal, crf_loss=crf_loss,
                     C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)

@@ -114,3 +114,12 @@ def test_graphed_inference_equals_eager(shdr):
     for _ in range(3):
         x = dev(quantised_image(rng, (1, 128, 96, 3)))
         np.testing.assert_array_equal(host(graphed(x)), host(eager(x)))
+
+
+def test_multi_stream_inference_equals_single_stream(shdr):
+    """batch slices on separate HIP streams: images are independent, results are bit-identical"""
+    ms = {k: build(shdr, k, 50 + i)[0] for i, k in enumerate(("deq", "lin", "hal", "ref"))}
+    one = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    two = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"], streams=2)
+    x = dev(quantised_image(np.random.default_rng(8), (5, 64, 96, 3)))       # uneven split: 3 + 2
+    np.testing.assert_array_equal(host(two(x)), host(one(x)))
