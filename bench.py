@@ -173,6 +173,8 @@ def main():
             return y
 
         reps = 3
+        eager(ldr)           # the caching allocator's pool of THIS stream (the timed leg may have run on side streams)
+        torch.cuda.synchronize()
         K.conv2d = timed_conv
         try:
             for _ in range(reps):
@@ -180,22 +182,30 @@ def main():
             torch.cuda.synchronize()
         finally:
             K.conv2d = orig
+        # one entry per conv call of ONE pass, timed as the median over the `reps` passes (a host-side hiccup --
+        # e.g. the runtime growing its signal pool inside hipEventRecord -- shows up as GPU idle time between
+        # the two events of whichever call it hits, in one pass only)
+        per_pass = len(records) // reps
+        calls = []
+        for i in range(per_pass):
+            var, fl, _, _, desc, nested = records[i]
+            ms = sorted(records[i + r * per_pass][2].elapsed_time(records[i + r * per_pass][3]) for r in range(reps))[reps // 2]
+            calls.append((var, fl, ms * 1e-3, desc, nested))
         if args.layers:
-            for var, fl, e0, e1, desc, nested in records[:len(records) // reps]:
-                ms = e0.elapsed_time(e1)
-                print("%-46s %-28s %8.3f ms %7.2f TF%s" % (var, desc, ms, fl / ms / 1e9, "  (nested GEMM, executed FLOPs)" if nested else ""),
-                      file=sys.stderr)
+            for var, fl, sec, desc, nested in calls:
+                print("%-46s %-28s %8.3f ms %7.2f TF%s" % (var, desc, sec * 1e3, fl / sec / 1e12,
+                                                         "  (nested GEMM, executed FLOPs)" if nested else ""), file=sys.stderr)
         # layers: top-level calls with the reference layer's algorithmic FLOPs; kernels: every launch of a conv
         # kernel (top-level direct convs + the GEMMs nested in Winograd layers, with the FLOPs they execute)
         layers, agg = {}, {}
-        for var, fl, e0, e1, _, nested in records:
-            sec = e0.elapsed_time(e1) * 1e-3
+        for var, fl, sec, _, nested in calls:
             if not nested:
                 a = layers.setdefault(var, [0.0, 0.0, 0])
                 a[0] += fl; a[1] += sec; a[2] += 1
             if nested or not var.startswith("winograd"):
                 a = agg.setdefault(var, [0.0, 0.0, 0])
                 a[0] += fl; a[1] += sec; a[2] += 1
+        reps = 1             # `calls` holds one pass
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[dom]
         achieved = fl / sec / 1e12
