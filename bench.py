@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-size", type=int, default=256)
     ap.add_argument("--single-stream", action="store_true", help="joint step: run deq / lin / hal on one stream")
+    ap.add_argument("--finetune-steps", type=int, default=2, help="timed fine-tuning steps per precision (0 = skip that leg)")
+    ap.add_argument("--finetune-batch", type=int, default=4)       # finetune_real_dataset.py:25
+    ap.add_argument("--finetune-size", type=int, default=1024)
     return ap.parse_args()
 
 
@@ -307,6 +310,48 @@ def main():
             "tflops_algorithmic_per_gpu": round(gflop_img * b * args.train_steps / tdt / 1e3, 2),
             "loss": round(loss, 5),
         }
+
+    # ---- fine-tuning leg (BASELINE configs[4]): the chained deq->lin->hal->ref step of finetune_real_dataset.py on
+    #      1024x1024 tiles, fp32 operands vs the fp16-MFMA-operand conv path (fp32 master weights / accumulation) ----
+    if args.finetune_steps > 0:
+        tout = step = None
+        torch.cuda.empty_cache()
+        fg = torch.Generator().manual_seed(5 + rank)
+        b, sz = args.finetune_batch, args.finetune_size
+        f_ldr = (torch.round(torch.rand((b, sz, sz, 3), generator=fg) * 255.0) / 255.0).cuda()
+        f_hdr = torch.rand((b, sz, sz, 3), generator=fg) * 1.5
+        f_hdr = (f_hdr / (1e-6 + f_hdr.mean(dim=(1, 2, 3), keepdim=True)) * 0.5).cuda()
+        gflop_img = 5360.0 * (sz / 1024.0) ** 2         # fwd 1785 GF/img, fwd+bwd ~3x
+        leg = {"workload": "BASELINE configs[4]: finetune_real_dataset.py step (deq+lin+hal+ref, fwd+bwd+Adam), batch=%d x "
+                           "%dx%d tiles per GPU; fp16 = fp16 operands of v_mfma_f32_16x16x32_f16 in every conv "
+                           "fwd/dgrad/wgrad, fp32 tensors in HBM, fp32 accumulate" % (b, sz, sz),
+               "n_gpus": world, "scaling": "weak", "steps": args.finetune_steps}
+        for prec in ("fp32", "fp16"):
+            torch.manual_seed(777)
+            nets4 = [pkg.dequantization_net.model(), pkg.linearization_net.model(), pkg.hallucination_net.model(),
+                     pkg.refinement_net.model()]
+            fstep = pkg.pipeline.FinetuneStep(*nets4, precision=prec, loss_scale=1.0 if prec == "fp32" else 0.25,
+                                              process_group=(dist.group.WORLD if dist is not None else None), world_size=world)
+            fstep(f_ldr, f_hdr)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.finetune_steps):
+                fout = fstep(f_ldr, f_hdr)
+            barrier()
+            fdt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([fdt], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                fdt = float(t.item())
+            floss = float(fout["loss_sum"].detach().sum())
+            assert floss == floss, "fine-tuning step produced NaN (%s)" % prec
+            leg[prec] = {"ms_per_step": round(fdt / args.finetune_steps * 1e3, 2),
+                         "images_per_s": round(b * world * args.finetune_steps / fdt, 3),
+                         "tflops_algorithmic_per_gpu": round(gflop_img * b * args.finetune_steps / fdt / 1e3, 2),
+                         "loss_sum": round(floss, 3)}
+            del fstep, nets4, fout
+            torch.cuda.empty_cache()
+        result["finetune"] = leg
 
     if rank == 0:
         print(json.dumps(result), flush=True)

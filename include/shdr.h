@@ -44,6 +44,14 @@ extern "C" {
 #define SHDR_ALGO_DIRECT  2  /* VALU direct convolution (any shape)                     */
 #define SHDR_ALGO_MFMA_REG 3 /* MFMA kernel with register-staged LDS fill (the LDS-DMA  */
                              /* variant is preferred whenever x2_scale == 1)           */
+/* Reduced-precision MFMA operands for BASELINE configs[4] ("finetune_real_dataset.py ... fp16 MFMA conv path"):
+ * tensors stay fp32 in HBM; activations and filters are rounded to nearest-even to fp16 (bf16) when they are
+ * packed into the operands of v_mfma_f32_16x16x32_{f16,bf16}; products accumulate in fp32.  Needs x2_scale == 1.
+ * Accepted by shdr_conv2d_fwd_f32 and, through the same descriptor, by shdr_conv2d_wgrad_f32. */
+#define SHDR_ALGO_MFMA_F16  4  /* force the MFMA path with fp16 operands                 */
+#define SHDR_ALGO_MFMA_BF16 5  /* force the MFMA path with bf16 operands                 */
+#define SHDR_ALGO_AUTO_F16  6  /* AUTO; fp16 operands wherever the MFMA path is taken    */
+#define SHDR_ALGO_AUTO_BF16 7  /* AUTO; bf16 operands wherever the MFMA path is taken    */
 
 const char* shdr_last_error(void);
 /* library / code-object version string, e.g. "libshdr 0.1 gfx950" */

@@ -59,13 +59,25 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, w, bias, stride, x2_scale, act1, cout_valid, algo):
-        y = K.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, algo=algo, cout_valid=cout_valid)
+        wf = w
+        if K.PRECISION != "fp32" and x2 is not None and x2_scale != 1.0:
+            # the reduced-precision kernels take x2_scale folded into the x2 rows of the filter
+            c1 = x.shape[3]
+            wf = torch.cat([w[:, :, :c1], w[:, :, c1:] * x2_scale], dim=2)
+        y = K.conv2d(x, wf, bias, stride=stride, x2=x2, x2_scale=x2_scale if wf is w else 1.0, act1=act1, algo=algo,
+                     cout_valid=cout_valid)
         ctx.save_for_backward(x, x2, w, y)
         ctx.meta = (stride, x2_scale, act1, bias is not None)
+        ctx.prec = K.PRECISION          # the backward kernels run at the precision of the forward
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        with K.precision(ctx.prec):
+            return Conv2dFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, x2, w, y = ctx.saved_tensors
         stride, x2_scale, act1, has_bias = ctx.meta
         dy = _c(dy)

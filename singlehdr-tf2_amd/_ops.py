@@ -33,6 +33,32 @@ def winograd_pays(cin, cout):
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
+ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
+
+# MFMA operand precision of the conv kernels (forward, dgrad, wgrad).  "fp32" is the parity path (exact-fp32 MFMA);
+# "fp16" / "bf16" is the reduced-precision path of BASELINE configs[4]: tensors stay fp32 in HBM, operands are rounded
+# when they are packed for v_mfma_f32_16x16x32_{f16,bf16}, accumulation is fp32.  Winograd is not used then.
+PRECISION = "fp32"
+_AUTO_ALGO = {"fp32": ALGO_AUTO, "fp16": ALGO_AUTO_F16, "bf16": ALGO_AUTO_BF16}
+
+
+class precision:
+    """with precision("fp16"): ...   -- scoped override of the conv operand precision"""
+
+    def __init__(self, name):
+        if name not in _AUTO_ALGO:
+            raise ValueError("precision must be one of %s" % sorted(_AUTO_ALGO))
+        self._name = name
+
+    def __enter__(self):
+        global PRECISION
+        self._prev, PRECISION = PRECISION, self._name
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self._prev
+        return False
 
 
 def same_pad(in_size, k, stride):
@@ -76,6 +102,8 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     `cout_valid` < w.shape[3] says the filter is zero-padded along Cout (to a multiple of 16 so
     that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored.
     `pad=(top, left)` / `out_hw=(Ho, Wo)` override the SAME rule (used by the strided dgrad)."""
+    if algo == ALGO_AUTO:
+        algo = _AUTO_ALGO[PRECISION]
     fused = scale is not None or shift is not None or residual is not None or act2 != ACT_NONE
     if not fused and pad is None and _needs_grad(x, x2, w, bias):   # fused epilogues are the inference path: never taped
         return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
@@ -395,6 +423,7 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
         raise ValueError("conv2d_wgrad: filter %s does not match x %s (+%d) / dz %s"
                          % (tuple(w_shape), tuple(x.shape), c2, tuple(dz.shape)))
     d = _conv_desc(x.shape, w_shape, stride, c2, x2_scale, None)
+    d.algo = _AUTO_ALGO[PRECISION]
     if tuple(dz.shape[:3]) != (x.shape[0], d.Ho, d.Wo):
         raise ValueError("conv2d_wgrad: dz spatial shape mismatch")
     dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)

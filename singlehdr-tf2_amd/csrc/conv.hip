@@ -46,7 +46,11 @@ struct ConvArgs {
   long w_bstride;  // filter elements between consecutive images (0: one filter for the batch)
   int no_dma;      // force the register-staged kernel (SHDR_ALGO_MFMA_REG)
   int cout_valid;  // channels actually stored (<= Cout; the filter may be zero-padded to Cout)
+  int prec;        // 0: exact fp32 MFMA; 1: fp16 / 2: bf16 MFMA operands (fp32 in HBM and LDS, fp32 accumulate)
 };
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int BK = 32;
 constexpr int SA = 34;  // A-tile row stride in dwords: bank(2*i+g) conflict-free, 8-byte aligned rows
@@ -335,7 +339,11 @@ typedef __attribute__((address_space(3))) void* shdr_lptr_t;
 template <int BM, int BN>
 __host__ __device__ constexpr int conv_dma_lds_bytes() { return 2 * (BM * BK + BK * BN) * 4; }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+//   * PREC = 1 / 2 (fp16 / bf16 MFMA operands, BASELINE configs[4]): the LDS image stays fp32 -- the same DMA,
+//     the same fragment reads -- and the 8 k values a lane group owns in a chunk (4g..4g+3, 16+4g..16+4g+3)
+//     are rounded to nearest-even and packed into ONE v_mfma_f32_16x16x32_{f16,bf16} operand: 16 MFMAs per chunk
+//     instead of 128, accumulation in fp32.  The kernel is then bound by the LDS / L2 feed, not by the matrix pipe.
+template <int BM, int BN, int WM, int WN, bool FAST, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TH = BM / 16;
@@ -491,6 +499,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
     constexpr bool WITH_NEXT = decltype(with_next)::value;
     const float* Ab = As + buf * BM * BK;
     const float* Bb = Bs + buf * BK * BN + b_row0;
+    if constexpr (PREC != 0) {
+      using frag_t = std::conditional_t<PREC == 1, f16x8, bf16x8>;
+      using elem_t = std::conditional_t<PREC == 1, _Float16, __bf16>;
+      float4 qa[MT][2];
+      float bv[8][NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        qa[mi][0] = *reinterpret_cast<const float4*>(Ab + a_rd[mi][0]);
+        qa[mi][1] = *reinterpret_cast<const float4*>(Ab + a_rd[mi][1]);
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bv[s][ni] = Bb[(16 * (s >> 2) + (s & 3)) * BN + b_col[ni]];
+      if constexpr (WITH_NEXT) dma_next(buf ^ 1);
+      frag_t pa[MT], wb[NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        pa[mi][0] = (elem_t)qa[mi][0].x; pa[mi][1] = (elem_t)qa[mi][0].y;
+        pa[mi][2] = (elem_t)qa[mi][0].z; pa[mi][3] = (elem_t)qa[mi][0].w;
+        pa[mi][4] = (elem_t)qa[mi][1].x; pa[mi][5] = (elem_t)qa[mi][1].y;
+        pa[mi][6] = (elem_t)qa[mi][1].z; pa[mi][7] = (elem_t)qa[mi][1].w;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wb[ni][s] = (elem_t)bv[s][ni];
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          if constexpr (PREC == 1)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], pa[mi], acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ni], pa[mi], acc[mi][ni], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
     float4 qa[MT][2];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) qa[mi][0] = *reinterpret_cast<const float4*>(Ab + a_rd[mi][0]);
@@ -593,7 +641,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN, bool FAST, int PREC = 0>
 int launch_mfma_dma_impl(ConvArgs& a, hipStream_t st) {
   constexpr int TH = BM / 16;
   a.tiles_x = (a.Wo + 15) / 16;
@@ -603,14 +651,14 @@ int launch_mfma_dma_impl(ConvArgs& a, hipStream_t st) {
   constexpr int lds = conv_dma_lds_bytes<BM, BN>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_dma_kernel<BM, BN, WM, WN, FAST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_dma_kernel<BM, BN, WM, WN, FAST, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, WM, WN, FAST>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, WM, WN, FAST, PREC>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_mfma_dma_kernel");
 }
 
@@ -640,6 +688,13 @@ int launch_mfma(ConvArgs& a, hipStream_t st) {
   const bool fast = (a.Ct % BK == 0) && (a.C2 == 0 || a.C1 % BK == 0);
   a.chunked = fast;
   a.nchunks = fast ? a.ntaps * (a.Ct / BK) : (a.K + BK - 1) / BK;
+  if (a.prec != 0) {
+    if (a.x2_scale != 1.0f)
+      return shdr::fail(SHDR_E_SHAPE, "conv2d: the fp16/bf16 MFMA path needs x2_scale == 1 (fold it into the filter)");
+    if (a.prec == 1)
+      return fast ? launch_mfma_dma_impl<BM, BN, WM, WN, true, 1>(a, st) : launch_mfma_dma_impl<BM, BN, WM, WN, false, 1>(a, st);
+    return fast ? launch_mfma_dma_impl<BM, BN, WM, WN, true, 2>(a, st) : launch_mfma_dma_impl<BM, BN, WM, WN, false, 2>(a, st);
+  }
   if (a.x2_scale == 1.0f && !a.no_dma)
     return fast ? launch_mfma_dma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_dma_impl<BM, BN, WM, WN, false>(a, st);
   return fast ? launch_mfma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_impl<BM, BN, WM, WN, false>(a, st);
@@ -719,6 +774,11 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
                        (!shift || shdr::aligned16(shift)) && (!residual || shdr::aligned16(residual));
   int algo = d->algo;
   if (algo == SHDR_ALGO_AUTO) algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
+  if (algo == SHDR_ALGO_AUTO_F16 || algo == SHDR_ALGO_AUTO_BF16) {   // reduced-precision operands where the MFMA path applies
+    a.prec = (mfma_ok && a.x2_scale == 1.0f) ? (algo == SHDR_ALGO_AUTO_F16 ? 1 : 2) : 0;
+    algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
+  }
+  if (algo == SHDR_ALGO_MFMA_F16 || algo == SHDR_ALGO_MFMA_BF16) { a.prec = algo == SHDR_ALGO_MFMA_F16 ? 1 : 2; algo = SHDR_ALGO_MFMA; }
   if (algo == SHDR_ALGO_MFMA_REG) { a.no_dma = 1; algo = SHDR_ALGO_MFMA; }
   if (algo == SHDR_ALGO_MFMA) {
     SHDR_REQUIRE(mfma_ok, SHDR_E_ALIGN,

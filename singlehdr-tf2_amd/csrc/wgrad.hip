@@ -22,6 +22,8 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -37,11 +39,15 @@ struct WgradArgs {
   int nslices;
   int tiles_m, tiles_n;
   float x_scale;
+  int prec;          // 0: exact fp32 MFMA, 1: fp16 operands, 2: bf16 operands
 };
 
 constexpr int PK = 32;  // pixels per chunk
 
-template <int BMc, int BNc, int WM, int WN>
+// PREC = 1 / 2: fp16 / bf16 MFMA operands (BASELINE configs[4]).  Same fp32 LDS image and the same fragment reads; the
+// 8 pixels {4s + g, s = 0..7} a lane group owns in a chunk are rounded and packed into one operand of
+// v_mfma_f32_16x16x32_{f16,bf16}: 1 MFMA per 16x16 tile and chunk instead of 8; fp32 accumulation and fp32 atomics.
+template <int BMc, int BNc, int WM, int WN, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   static_assert(WM * WN <= 4, "at most 4 computing waves (the others only feed the DMA)");
   constexpr int MT = BMc / WM / 16;   // 16-ci groups per computing wave
@@ -151,6 +157,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   auto compute_chunk = [&](int buf) {
     const float* Xb = Xs + buf * PK * BMc + fg * BMc;
     const float* Zb = Zs + buf * PK * BNc + fg * BNc;
+    if constexpr (PREC != 0) {
+      using frag_t = std::conditional_t<PREC == 1, f16x8, bf16x8>;
+      using elem_t = std::conditional_t<PREC == 1, _Float16, __bf16>;
+      frag_t xf[MT], zf[NT];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) xf[mi][s] = (elem_t)Xb[4 * s * BMc + xcol[mi]];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) zf[ni][s] = (elem_t)Zb[4 * s * BNc + zcol[ni]];
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          if constexpr (PREC == 1)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mi], zf[ni], acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mi], zf[ni], acc[mi][ni], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < PK / 4; ++s) {   // pixel p = 4*s + fg of the chunk
       float xa[MT], zb[NT];
@@ -259,14 +287,14 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
   }
 }
 
-template <int BMc, int BNc, int WM, int WN>
-int launch_wgrad(WgradArgs& a, hipStream_t st) {
+template <int BMc, int BNc, int WM, int WN, int PREC>
+int launch_wgrad_prec(WgradArgs& a, hipStream_t st) {
   a.tiles_m = (a.Cx + BMc - 1) / BMc;
   a.tiles_n = (a.Cout + BNc - 1) / BNc;
   constexpr int lds = 2 * PK * (BMc + BNc) * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<BMc, BNc, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<BMc, BNc, WM, WN, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
@@ -280,9 +308,16 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   a.slice = (int)slice;
   a.nslices = (int)((a.npix + slice - 1) / slice);
   if (a.nslices > 65535) return shdr::fail(SHDR_E_SHAPE, "wgrad: too many pixel slices");
-  hipLaunchKernelGGL((wgrad_mfma_kernel<BMc, BNc, WM, WN>), dim3((unsigned)tiles, (unsigned)a.nslices), dim3(256),
+  hipLaunchKernelGGL((wgrad_mfma_kernel<BMc, BNc, WM, WN, PREC>), dim3((unsigned)tiles, (unsigned)a.nslices), dim3(256),
                      lds, st, a);
   return shdr::check_launch("wgrad_mfma_kernel");
+}
+
+template <int BMc, int BNc, int WM, int WN>
+int launch_wgrad(WgradArgs& a, hipStream_t st) {
+  if (a.prec == 1) return launch_wgrad_prec<BMc, BNc, WM, WN, 1>(a, st);
+  if (a.prec == 2) return launch_wgrad_prec<BMc, BNc, WM, WN, 2>(a, st);
+  return launch_wgrad_prec<BMc, BNc, WM, WN, 0>(a, st);
 }
 
 template <int BMc>
@@ -318,13 +353,16 @@ extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, 
   a.x_scale = which ? d->x2_scale : 1.0f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool mfma_ok = (a.Cx % 16 == 0) && (a.Cout % 16 == 0) && shdr::aligned16(x) && shdr::aligned16(dz);
+  a.prec = (d->algo == SHDR_ALGO_MFMA_F16 || d->algo == SHDR_ALGO_AUTO_F16) ? 1
+           : (d->algo == SHDR_ALGO_MFMA_BF16 || d->algo == SHDR_ALGO_AUTO_BF16) ? 2 : 0;
   if (mfma_ok && d->algo != SHDR_ALGO_DIRECT) {
     if (a.Cx % 128 == 0) return dispatch_n<128>(a, st);
     if (a.Cx % 64 == 0) return dispatch_n<64>(a, st);
     if (a.Cx % 32 == 0) return dispatch_n<32>(a, st);
     return dispatch_n<16>(a, st);
   }
-  SHDR_REQUIRE(d->algo != SHDR_ALGO_MFMA, SHDR_E_ALIGN, "wgrad: MFMA path needs Cin%%16==0 and Cout%%16==0");
+  SHDR_REQUIRE(d->algo != SHDR_ALGO_MFMA && d->algo != SHDR_ALGO_MFMA_F16 && d->algo != SHDR_ALGO_MFMA_BF16, SHDR_E_ALIGN,
+               "wgrad: MFMA path needs Cin%%16==0 and Cout%%16==0");
   a.slice = 1024;
   a.nslices = (a.npix + a.slice - 1) / a.slice;
   hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)a.nslices), dim3(256), 0, st, a);

@@ -236,11 +236,19 @@ class FinetuneStep:
     LEARNING_RATE = 1e-5   # finetune_real_dataset.py:24
     THRESHOLD = 0.12       # finetune_real_dataset.py:26
 
-    def __init__(self, deq, lin, hal, ref, lr=None, process_group=None, world_size=1):
+    def __init__(self, deq, lin, hal, ref, lr=None, process_group=None, world_size=1, precision="fp32",
+                 loss_scale=1.0):
+        """precision: MFMA operand precision of every conv forward / dgrad / wgrad of the step -- "fp32" (parity
+        path) or "fp16" / "bf16" (BASELINE configs[4]: fp32 master weights, fp32 activations in HBM, fp32
+        accumulation; operands rounded inside the kernels).  loss_scale: static scale applied to the seed gradient
+        and divided out of the flat gradient before the collective.  The loss here is a SUM over pixels, so output
+        gradients are O(1)..O(1e3) and need no up-scaling; 256 overflows fp16 at 512x512 tiles (measured)."""
         self._deq, self._lin, self._hal, self._ref = deq, lin, hal, ref
         self.params = FlatParams([deq, lin, hal, ref])
         self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
         self.pg, self.world = process_group, world_size
+        self.precision, self.loss_scale = precision, float(loss_scale)
+        self.skipped_steps = 0
 
     def forward(self, ldr, hdr):
         pred_deq = self._deq(ldr, training=True)
@@ -260,11 +268,20 @@ class FinetuneStep:
 
     def __call__(self, ldr, hdr, apply=True):
         self.params.zero_grad()
-        out = self.forward(ldr, hdr)
-        out["loss_sum"].sum().backward()
+        with K.precision(self.precision):
+            out = self.forward(ldr, hdr)
+            (out["loss_sum"].sum() * self.loss_scale).backward()
+        if self.loss_scale != 1.0:
+            self.params.grad.mul_(1.0 / self.loss_scale)
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.precision == "fp16" and not bool(torch.isfinite(self.params.grad.sum())):
+            # an fp16 operand overflowed (|value| > 65504).  Checked after the collective, so every rank sees it: drop
+            # the step like a dynamic loss scaler would.  The batch-summed loss makes output gradients GROW with the
+            # tile size, so the remedy is loss_scale < 1.
+            self.skipped_steps += 1
+            return out
         if apply:
             self.optimizer.step()
         return out

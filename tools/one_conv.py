@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--algo", type=int, default=0, help="SHDR_ALGO_* (4: fp16 MFMA operands, 5: bf16)")
     a = ap.parse_args()
     K = importlib.import_module("singlehdr-tf2_amd")._ops
     torch.manual_seed(0)
@@ -32,17 +33,21 @@ def main():
     w = torch.randn(a.k, a.k, a.cin + a.c2, a.cout, device="cuda") * 0.02
     b = torch.randn(a.cout, device="cuda")
     for _ in range(3):
-        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU)
+        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU, algo=a.algo)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(a.reps):
-        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU)
+        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU, algo=a.algo)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     ho = -(-a.hw // a.stride)
     fl = 2.0 * a.n * ho * ho * (a.cin + a.c2) * a.cout * a.k * a.k
+    if a.algo in (4, 5):
+        K.WINOGRAD = False
+        ref = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU)
+        print("  rel err vs fp32 path: %.3g" % float((y - ref).abs().max() / ref.abs().max()))
     print("conv %dx%dx%d %d+%d->%d k%d s%d: %.4f ms  %.2f TFLOP/s  (y mean %.4g)"
           % (a.n, a.hw, a.hw, a.cin, a.c2, a.cout, a.k, a.stride, ms, fl / ms / 1e9, float(y.mean())))
 
