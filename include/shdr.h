@@ -57,6 +57,10 @@ const char* shdr_last_error(void);
 /* library / code-object version string, e.g. "libshdr 0.1 gfx950" */
 const char* shdr_version(void);
 
+/* CRC-32C (Castagnoli) of `n` bytes, continuing from `crc` (0 to start).  Host-side helper of the TensorFlow
+ * tensor-bundle checkpoint reader / writer (the format tf_utils.py:149-169 saves). */
+uint32_t shdr_crc32c(const void* data, uint64_t n, uint32_t crc);
+
 /* TF 'SAME' rule: out = ceil(in/stride); total = max((out-1)*stride+k-in,0);
  * *pad_before = total/2 (extra cell goes to the bottom/right). */
 int shdr_same_pad(int in_size, int k, int stride, int* out_size, int* pad_before);
