@@ -274,6 +274,23 @@ int shdr_mean_norm_fwd_f32(const float* r, const float* sum, float* out, int B, 
 int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, float* dr, int B,
                            int64_t n_per_sample, float eps, float target, void* stream);
 
+/* ---- inference-tool image plumbing (test_real_refinement.py:119-155) -------------- */
+/* y[p][c] = x[p][reverse ? 2-c : c] / 255: the decoded 8-bit image as float in [0,1] (:125). */
+int shdr_u8_to_unit_f32(const uint8_t* x, float* y, int64_t npix, int reverse_channels, void* stream);
+/* cv2.resize(..., interpolation=cv2.INTER_CUBIC) on NHWC float (:133, :146): A = -0.75 bicubic, half-pixel
+ * centres, replicated border, no antialiasing. */
+int shdr_resize_cubic_f32(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* np.pad(x, pad, 'symmetric') over H and W (:136): y [N, H+2*pad, W+2*pad, C]. */
+int shdr_pad_symmetric_f32(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+/* float RGB -> Radiance RGBE bytes [npix,4], the pixel conversion of cv2.imwrite("*.hdr") (:150);
+ * reverse_channels != 0 reads the pixel as BGR. */
+int shdr_rgbe_encode_f32(const float* x, uint8_t* y, int64_t npix, int reverse_channels, void* stream);
+
+/* Host-side Radiance scanline RLE of an RGBE image [height][width][4] (the adaptive run-length form of "*.hdr"
+ * files, :150).  Returns the number of bytes written to `out`, or -1 (see shdr_last_error) if `capacity` is less than
+ * height * (4 + 4 * (width + width / 127 + 2)). */
+int64_t shdr_rgbe_rle_encode(const uint8_t* rgbe, int width, int height, uint8_t* out, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,11 @@ class ConvDesc(ctypes.Structure):
 SIGNATURES = {
     "shdr_last_error": (ctypes.c_char_p, []),
     "shdr_version": (ctypes.c_char_p, []),
+    "shdr_u8_to_unit_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_resize_cubic_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_pad_symmetric_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_rgbe_encode_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_rgbe_rle_encode": (c_i64, [c_ptr, c_int, c_int, c_ptr, c_i64]),
     "shdr_crc32c": (ctypes.c_uint32, [c_ptr, ctypes.c_uint64, ctypes.c_uint32]),
     "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),

@@ -793,3 +793,48 @@ def conv2d_winograd(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2
     _lib.check(lib.shdr_winograd_output_f32(_ptr(m), _ptr(y), _ptr(_d(bias)), _ptr(_d(scale)), _ptr(_d(shift)), n, h, w, cout,
                                             act1, act2, _stream()), "shdr_winograd_output_f32")
     return y
+
+
+# ---------------------------------------------------------------------------
+# image plumbing of the inference tool (test_real_refinement.py:119-155), see csrc/imageio.hip
+# ---------------------------------------------------------------------------
+def u8_to_unit(img_u8, reverse_channels=False):
+    """uint8 [..., 3] on the device -> float32 in [0,1]; optionally reversing the channel order (np.flip(img, -1))"""
+    lib = _lib.load()
+    if not (isinstance(img_u8, torch.Tensor) and img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.is_contiguous()
+            and img_u8.shape[-1] == 3):
+        raise TypeError("u8_to_unit: expected a contiguous uint8 device tensor [..., 3]")
+    y = torch.empty(img_u8.shape, device=img_u8.device, dtype=torch.float32)
+    _lib.check(lib.shdr_u8_to_unit_f32(_ptr(img_u8), _ptr(y), img_u8.numel() // 3, int(reverse_channels), _stream()),
+               "shdr_u8_to_unit_f32")
+    return y
+
+
+def resize_cubic(x, out_hw):
+    """cv2.resize(x, (Wo, Ho), interpolation=cv2.INTER_CUBIC) on an NHWC float tensor"""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    n, h, w, c = x.shape
+    ho, wo = int(out_hw[0]), int(out_hw[1])
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_resize_cubic_f32(_ptr(x), _ptr(y), n, h, w, c, ho, wo, _stream()), "shdr_resize_cubic_f32")
+    return y
+
+
+def pad_symmetric(x, pad):
+    """np.pad(x, ((0,0),(pad,pad),(pad,pad),(0,0)), 'symmetric')"""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, h + 2 * pad, w + 2 * pad, c), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_pad_symmetric_f32(_ptr(x), _ptr(y), n, h, w, c, int(pad), _stream()), "shdr_pad_symmetric_f32")
+    return y
+
+
+def rgbe_encode(x, reverse_channels=False):
+    """float [..., 3] -> Radiance RGBE bytes uint8 [..., 4]"""
+    lib = _lib.load()
+    x, npix = _pix3(x, "x")
+    y = torch.empty(tuple(x.shape[:-1]) + (4,), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.shdr_rgbe_encode_f32(_ptr(x), _ptr(y), npix, int(reverse_channels), _stream()), "shdr_rgbe_encode_f32")
+    return y

@@ -28,6 +28,7 @@ SOURCES = {
     "pool.hip": [],
     "crf.hip": [],
     "glue.hip": [],
+    "imageio.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + INCLUDE, "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,72 @@
+"""File formats and CPU restatements of the inference tool's image plumbing (test_real_refinement.py:119-155)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import imageio as O
+
+pkg = importlib.import_module("singlehdr-tf2_amd")
+IO = pkg.hdr_io
+
+
+def test_rgbe_pixel_known_answers():
+    px = np.array([[1.0, 0.5, 0.25], [0.0, 0.0, 0.0], [1e-33, 0, 0], [3.0, 200.0, 0.7], [0.999, 0.1, -5.0]], dtype=np.float32)
+    got = O.rgbe_encode(px)
+    assert got[0].tolist() == [128, 64, 32, 129]            # 1.0 = 0.5 * 2^1 -> scale 128, exponent 1 + 128
+    assert got[1].tolist() == [0, 0, 0, 0] and got[2].tolist() == [0, 0, 0, 0]
+    assert got[3].tolist() == [3, 200, 0, 136]              # 200 = 0.78125 * 2^8 -> one mantissa unit = 1.0
+    assert got[4, 2] == 0                                   # negative radiance clamps to 0
+    back = IO.rgbe_decode(got)
+    assert np.all(np.abs(back - np.maximum(px, 0)) <= np.maximum(px, 0).max(axis=1, keepdims=True) / 128 + 1e-30)
+
+
+def test_rle_known_scanline_and_round_trip(tmp_path):
+    flat = np.tile(np.array([[10, 20, 30, 129]], dtype=np.uint8), (8, 1))[None]              # 1 x 8, constant
+    assert IO.rle_encode(flat) == bytes([2, 2, 0, 8, 136, 10, 136, 20, 136, 30, 136, 129])
+    rng = np.random.default_rng(0)
+    for h, w in ((3, 5), (4, 8), (5, 300), (2, 1000)):
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        img[:, : w // 3] = img[:, :1]                       # long runs
+        img[1, :, 3] = 128                                  # a constant exponent row
+        img[0, w // 2:w // 2 + 3, 1] = 7                    # a run shorter than the minimum run length
+        path = str(tmp_path / ("t%d.hdr" % w))
+        IO.write_hdr(path, img)
+        head = open(path, "rb").read(64)
+        assert head.startswith(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        assert np.array_equal(IO.read_hdr(path), IO.rgbe_decode(img))
+    big = np.zeros((64, 512, 4), dtype=np.uint8)
+    big[..., 3] = 128
+    assert len(IO.rle_encode(big)) < big.size // 20         # runs really are compressed
+    with pytest.raises(ValueError):
+        IO.write_hdr(str(tmp_path / "bad.hdr"), np.zeros((4, 4, 3), dtype=np.float32))
+
+
+def test_cubic_resize_restatement_properties():
+    rng = np.random.default_rng(1)
+    x = rng.random((2, 9, 11, 3)).astype(np.float32)
+    assert np.array_equal(O.resize_cubic(x, (9, 11)), x)                                     # same size: tap 1 has weight 1
+    const = np.full((1, 7, 5, 2), 0.37, dtype=np.float32)
+    assert np.allclose(O.resize_cubic(const, (64, 64)), 0.37, atol=1e-6)                     # weights sum to 1
+    # OpenCV's coefficients (A = -0.75; NOT Catmull-Rom, so lines are not reproduced exactly): t = 0, 0.25, 0.5
+    assert np.allclose(O._cubic_weights(8, 8)[1], [[0, 1, 0, 0]] * 8)
+    assert np.allclose(O._cubic_weights(3, 6)[1][1], [-0.10546875, 0.87890625, 0.26171875, -0.03515625])   # t = 0.25
+    idx, w = O._cubic_weights(5, 5 * 4 // 2)               # scale 0.5: every source coordinate is k + 0.5 - ... -> t = 0.25/0.75
+    assert np.allclose(w[0], w[1][::-1])                   # w(t) mirrored = w(1 - t)
+    half = O._cubic_weights(4, 2)[1]                       # scale 2: t = 0.5
+    assert np.allclose(half, [[-0.09375, 0.59375, 0.59375, -0.09375]] * 2)
+    assert idx.min() == 0 and idx.max() == 4               # replicated border: taps are clamped into the image
+
+
+def test_symmetric_pad_and_image_reader(tmp_path):
+    x = np.arange(2 * 3 * 4 * 1, dtype=np.float32).reshape(2, 3, 4, 1)
+    y = O.pad_symmetric(x, 2)
+    assert y.shape == (2, 7, 8, 1) and y[0, 0, 0, 0] == x[0, 1, 1, 0] and y[0, 1, 2, 0] == x[0, 0, 0, 0]
+    assert y[0, -1, -1, 0] == x[0, -2, -2, 0]
+    from PIL import Image
+    rgb = (np.random.default_rng(2).random((20, 30, 3)) * 255).astype(np.uint8)
+    Image.fromarray(rgb).save(str(tmp_path / "a.png"))
+    assert np.array_equal(IO.read_ldr(str(tmp_path / "a.png")), rgb)
+    Image.fromarray(rgb[..., 0]).save(str(tmp_path / "g.jpg"), quality=95)
+    g = IO.read_ldr(str(tmp_path / "g.jpg"))
+    assert g.shape == (20, 30, 3) and g.dtype == np.uint8 and np.array_equal(g[..., 0], g[..., 2])
