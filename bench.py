@@ -302,6 +302,33 @@ def main():
         assert loss == loss, "joint step produced NaN"
         # algorithmic FLOPs per image: fwd 102.1 + 2 x VGG 24.39, bwd 2 x 102.1 + 24.39 GF at 256^2
         gflop_img = 379.5 * (sz / 256.0) ** 2
+        # the batch builder of that step (joint_training.py:26-69): exposure + noise + CRF + JPEG round trip + loss mask on the
+        # device, with the libjpeg-on-host round trip the reference pays (Pillow links the same libjpeg-turbo) beside it
+        cam = pkg.camera.CameraPipeline(seed=1 + rank)
+        crf = torch.cumsum(torch.rand((b, 1024), generator=tg), dim=1)
+        crf = ((crf - crf[:, :1]) / (crf[:, -1:] - crf[:, :1])).cuda()
+        expo = (0.5 + 2.0 * torch.rand((b,), generator=tg)).cuda()
+        cam(hdr_t.cuda(), crf, expo)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(5):
+            cam_out = cam(hdr_t.cuda(), crf, expo)
+        torch.cuda.synchronize()
+        cam_ms = (time.perf_counter() - c0) / 5 * 1e3
+        host_jpeg_ms = None
+        if rank == 0:
+            try:
+                import io
+                from PIL import Image
+                u8 = torch.round(cam_out[0] * 255.0).to(torch.uint8).cpu().numpy()
+                c0 = time.perf_counter()
+                for i, qq in enumerate(pkg.camera.jpeg_qualities(b)):
+                    buf = io.BytesIO()
+                    Image.fromarray(u8[i]).save(buf, format="JPEG", quality=qq, subsampling=2)
+                    np.array(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+                host_jpeg_ms = (time.perf_counter() - c0) * 1e3
+            except ImportError:
+                pass
         result["joint_train"] = {
             "workload": "BASELINE configs[3]: joint_training.py step, batch=%d x %dx%d per GPU, fp32, "
                         "1 all-reduce(SUM) of %d fp32 gradients" % (b, sz, sz, step.params.num_params),
@@ -309,6 +336,8 @@ def main():
             "images_per_s": round(b * world * args.train_steps / tdt, 2), "n_gpus": world, "scaling": "weak",
             "tflops_algorithmic_per_gpu": round(gflop_img * b * args.train_steps / tdt / 1e3, 2),
             "loss": round(loss, 5),
+            "camera_pipeline_ms_per_batch": round(cam_ms, 3),
+            "host_libjpeg_round_trip_ms_per_batch": None if host_jpeg_ms is None else round(host_jpeg_ms, 2),
         }
 
     # ---- fine-tuning leg (BASELINE configs[4]): the chained deq->lin->hal->ref step of finetune_real_dataset.py on

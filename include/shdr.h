@@ -291,6 +291,21 @@ int shdr_rgbe_encode_f32(const float* x, uint8_t* y, int64_t npix, int reverse_c
  * height * (4 + 4 * (width + width / 127 + 2)). */
 int64_t shdr_rgbe_rle_encode(const uint8_t* rgbe, int width, int height, uint8_t* out, int64_t capacity);
 
+/* ---- camera-pipeline simulator (joint_training.py:26-69 `_preprocessing`) ------------- */
+/* Philox4x32-10 block function (host): the counter-based generator the noise kernel uses; exported so that tests can
+ * check the published known-answer vectors. */
+int shdr_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* hdr_t = relu(hdr*t + N(0,1)*(sigma_s*hdr*t) + sigma_c*N(0,1)), sigma_s = 0.08/6*U, sigma_c = 0.005*U per (sample,
+ * channel) (:30-40); clipped = min(hdr_t, 1) (:43).  hdr [N,H,W,3], t [N].  Stateless: the same seed gives the same
+ * noise field for any launch geometry. */
+int shdr_camera_expose_f32(const float* hdr, const float* t, float* hdr_t, float* clipped, int N, int H, int W,
+                           uint64_t seed, void* stream);
+/* jpeg = tf.cast(tf.image.adjust_jpeg_quality(uint8(round(ldr*255)), quality[n]), float32) / 255 (:46-52) -- a
+ * baseline-JPEG round trip (4:2:0, islow DCT, fancy upsampling) in libjpeg's integer arithmetic, bit for bit -- and
+ * loss_mask [N] (:54-63; may be NULL).  H % 16 == W % 16 == 0.  ws_planes: N*H*W*3/2 bytes, ws_counts: 2*N int32. */
+int shdr_jpeg_round_trip_f32(const float* ldr, const int32_t* quality, float* jpeg, float* loss_mask,
+                             uint8_t* ws_planes, int32_t* ws_counts, int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -838,3 +838,37 @@ def rgbe_encode(x, reverse_channels=False):
     y = torch.empty(tuple(x.shape[:-1]) + (4,), device=x.device, dtype=torch.uint8)
     _lib.check(lib.shdr_rgbe_encode_f32(_ptr(x), _ptr(y), npix, int(reverse_channels), _stream()), "shdr_rgbe_encode_f32")
     return y
+
+
+# ---------------------------------------------------------------------------
+# camera-pipeline simulator (joint_training.py:26-69), see csrc/camera.hip
+# ---------------------------------------------------------------------------
+def camera_expose(hdr, t, seed):
+    """(hdr_t, clipped_hdr_t) of joint_training.py:30-43: exposure, shot + read noise, relu, clip to [0,1]"""
+    lib = _lib.load()
+    hdr, npix = _pix3(hdr, "hdr")
+    t = _chk(_d(t), "t").reshape(-1)
+    n, h, w, _ = hdr.shape
+    if t.numel() != n:
+        raise ValueError("camera_expose: t must have one exposure per sample")
+    hdr_t, clipped = torch.empty_like(hdr), torch.empty_like(hdr)
+    _lib.check(lib.shdr_camera_expose_f32(_ptr(hdr), _ptr(t), _ptr(hdr_t), _ptr(clipped), n, h, w, int(seed) & (2 ** 64 - 1),
+                                          _stream()), "shdr_camera_expose_f32")
+    return hdr_t, clipped
+
+
+def jpeg_round_trip(ldr, quality):
+    """(jpeg_img_float, loss_mask [b,1,1,1]) of joint_training.py:46-63; `quality`: one int per sample"""
+    lib = _lib.load()
+    ldr, npix = _pix3(ldr, "ldr")
+    n, h, w, _ = ldr.shape
+    q = torch.as_tensor(list(quality), dtype=torch.int32).to(ldr.device) if not isinstance(quality, torch.Tensor) else quality
+    if q.dtype != torch.int32 or q.numel() != n or not q.is_cuda:
+        raise ValueError("jpeg_round_trip: quality must be %d int32 values" % n)
+    jpeg = torch.empty_like(ldr)
+    mask = torch.empty((n, 1, 1, 1), device=ldr.device, dtype=torch.float32)
+    planes = torch.empty(n * h * w * 3 // 2, device=ldr.device, dtype=torch.uint8)
+    counts = torch.empty(2 * n, device=ldr.device, dtype=torch.int32)
+    _lib.check(lib.shdr_jpeg_round_trip_f32(_ptr(ldr), _ptr(q), _ptr(jpeg), _ptr(mask), _ptr(planes), _ptr(counts), n, h, w,
+                                            _stream()), "shdr_jpeg_round_trip_f32")
+    return jpeg, mask

@@ -29,6 +29,7 @@ SOURCES = {
     "crf.hip": [],
     "glue.hip": [],
     "imageio.hip": [],
+    "camera.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + INCLUDE, "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]
