@@ -306,6 +306,12 @@ int shdr_camera_expose_f32(const float* hdr, const float* t, float* hdr_t, float
 int shdr_jpeg_round_trip_f32(const float* ldr, const int32_t* quality, float* jpeg, float* loss_mask,
                              uint8_t* ws_planes, int32_t* ws_counts, int N, int H, int W, void* stream);
 
+/* HDR-Real record augmentation (finetune_real_dataset.py:49-61): per sample,
+ * y = rot90(flip_left_right(x) if flip[n] else x, k = rot[n]) / divisor on square NHWC images [N,S,S,C]
+ * (tf.image.rot90 = counter-clockwise). */
+int shdr_flip_rot90_f32(const float* x, float* y, const int32_t* flip, const int32_t* rot, int N, int S, int C,
+                        float divisor, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

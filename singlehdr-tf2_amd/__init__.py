@@ -9,7 +9,7 @@ names, or import them from this package.  All arithmetic runs in libshdr.so
 """
 from . import _lib, _ops, _autograd, _layers  # noqa: F401
 from . import dequantization_net, linearization_net, hallucination_net, refinement_net  # noqa: F401
-from . import vgg16, tf_utils, pipeline, tf_checkpoint, hdr_io, camera  # noqa: F401
+from . import vgg16, tf_utils, pipeline, tf_checkpoint, hdr_io, camera, tfrecord  # noqa: F401
 
 __all__ = ["dequantization_net", "linearization_net", "hallucination_net", "refinement_net",
-           "vgg16", "tf_utils", "pipeline", "tf_checkpoint", "hdr_io", "camera"]
+           "vgg16", "tf_utils", "pipeline", "tf_checkpoint", "hdr_io", "camera", "tfrecord"]

@@ -872,3 +872,19 @@ def jpeg_round_trip(ldr, quality):
     _lib.check(lib.shdr_jpeg_round_trip_f32(_ptr(ldr), _ptr(q), _ptr(jpeg), _ptr(mask), _ptr(planes), _ptr(counts), n, h, w,
                                             _stream()), "shdr_jpeg_round_trip_f32")
     return jpeg, mask
+
+
+def flip_rot90(x, flip, rot, divisor=1.0):
+    """per-sample rot90(flip_left_right(x) if flip else x, k) / divisor on square NHWC images; flip / rot: int32 [N] on the device"""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    n, h, w, c = x.shape
+    if h != w:
+        raise ValueError("flip_rot90: square images only, got %dx%d" % (h, w))
+    for t, nm in ((flip, "flip"), (rot, "rot")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int32 and t.numel() == n):
+            raise TypeError("flip_rot90: %s must be %d int32 values on the device" % (nm, n))
+    y = torch.empty_like(x)
+    _lib.check(lib.shdr_flip_rot90_f32(_ptr(x), _ptr(y), _ptr(flip), _ptr(rot), n, h, c, float(divisor), _stream()),
+               "shdr_flip_rot90_f32")
+    return y

@@ -132,3 +132,39 @@ extern "C" int shdr_rgbe_encode_f32(const float* x, uint8_t* y, int64_t npix, in
   hipLaunchKernelGGL(rgbe_encode_kernel, dim3(shdr::stream_grid(npix)), dim3(256), 0, S(stream), x, y, (long)npix, reverse_channels);
   return shdr::check_launch("rgbe_encode");
 }
+
+// ---- HDR-Real record augmentation (finetune_real_dataset.py:51-61): per-sample horizontal flip, then a counter-clockwise
+//      rotation by k * 90 degrees (tf.image.rot90), and a scalar divide (ref_LDR / 255.0, :49) in the same pass ----------
+namespace {
+__global__ __launch_bounds__(256) void flip_rot90_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const int* __restrict__ flip, const int* __restrict__ rot, int N,
+                                                         int S, int C, float divisor) {
+  const long per = (long)S * S * C;
+  const long total = (long)N * per;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e / per);
+    long r = e - (long)n * per;
+    const int c = (int)(r % C);
+    r /= C;
+    const int j = (int)(r % S), i = (int)(r / S);          // output pixel (i, j)
+    int si, sj;                                            // pixel of the flipped image that lands there
+    switch (rot[n] & 3) {
+      case 1: si = j; sj = S - 1 - i; break;               // np.rot90(m, 1)[i][j] = m[j][S-1-i]
+      case 2: si = S - 1 - i; sj = S - 1 - j; break;
+      case 3: si = S - 1 - j; sj = i; break;
+      default: si = i; sj = j; break;
+    }
+    if (flip[n]) sj = S - 1 - sj;                          // flip_left_right was applied first
+    y[e] = x[((long)n * S * S + (long)si * S + sj) * C + c] / divisor;
+  }
+}
+}  // namespace
+
+extern "C" int shdr_flip_rot90_f32(const float* x, float* y, const int32_t* flip, const int32_t* rot, int N, int side, int C,
+                                   float divisor, void* stream) {
+  SHDR_REQUIRE(x && y && flip && rot, SHDR_E_NULL, "flip_rot90: null pointer");
+  SHDR_REQUIRE(N > 0 && side > 0 && C > 0 && divisor != 0.0f, SHDR_E_SHAPE, "flip_rot90: bad shape (square images only)");
+  hipLaunchKernelGGL(flip_rot90_kernel, dim3(shdr::stream_grid((long)N * side * side * C)), dim3(256), 0, S(stream), x, y, flip,
+                     rot, N, side, C, divisor);
+  return shdr::check_launch("flip_rot90");
+}

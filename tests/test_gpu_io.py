@@ -83,3 +83,45 @@ def test_file_loop_matches_the_oracle_chain(shdr, emor_table, tmp_path):
         assert got.shape == (h, w, 3)
         step = want.max(axis=-1, keepdims=True) / 128 + 1e-6                          # one RGBE mantissa unit per pixel
         assert np.all(np.abs(got - want) <= 1.01 * step + 1e-4 * want.max())
+
+
+def test_flip_rot90_matches_tf_semantics(shdr):
+    K = shdr._ops
+    rng = np.random.default_rng(9)
+    x = rng.random((10, 12, 12, 3)).astype(np.float32) * 255
+    flip = np.array([0, 1, 0, 1, 0, 1, 0, 1, 0, 1], dtype=np.int32)
+    rot = np.array([0, 0, 1, 1, 2, 2, 3, 3, 4, 4], dtype=np.int32)       # k = int(u*4 + 0.5) reaches 4 (= 0)
+    got = K.flip_rot90(dev(x), dev(flip), dev(rot), 255.0).cpu().numpy()
+    for i in range(10):
+        img = x[i][:, ::-1] if flip[i] else x[i]                          # tf.image.flip_left_right
+        want = np.rot90(img, int(rot[i]), axes=(0, 1)) / np.float32(255.0)   # tf.image.rot90: counter-clockwise
+        assert np.array_equal(got[i], want), i
+
+
+def test_hdr_real_dataset_iterates_device_batches(shdr, tmp_path):
+    """records written in the layout of convert_to_tf_record.py:62-66, read back as finetune_real_dataset.py:34-78 does"""
+    T = shdr.tfrecord
+    rng = np.random.default_rng(10)
+    patches = [(rng.random((256, 256, 3)).astype(np.float32) * 255, (rng.random((256, 256, 3)) ** 3 * 40).astype(np.float32))
+               for _ in range(6)]
+    for f in range(2):
+        T.write_records(str(tmp_path / ("train_64_%04d.tfrecords" % f)),
+                        [T.make_example({"ref_HDR": h.tobytes(), "ref_LDR": l.tobytes()}) for l, h in patches[3 * f:3 * f + 3]])
+    plain = list(T.HdrRealDataset(str(tmp_path), batch_size=4, augment=False, shuffle_buffer=0))
+    assert [tuple(b[0].shape) for b in plain] == [(4, 256, 256, 3), (2, 256, 256, 3)]             # drop_remainder=False
+    ldr = torch.cat([b[0] for b in plain]).cpu().numpy()
+    hdr = torch.cat([b[1] for b in plain]).cpu().numpy()
+    for i, (l, h) in enumerate(patches):
+        assert np.array_equal(ldr[i], l / np.float32(255.0))
+        want = h / (np.float32(1e-6) + h.mean(dtype=np.float64).astype(np.float32)) * np.float32(0.5)
+        assert np.abs(hdr[i] - want).max() <= 2e-6 * want.max()
+    aug = list(T.HdrRealDataset(str(tmp_path), batch_size=4, seed=3))
+    assert sum(b[0].shape[0] for b in aug) == 6
+    a_ldr = torch.cat([b[0] for b in aug]).cpu().numpy()
+    # every augmented patch is one of the 8 flips / rotations of exactly one source patch
+    for img in a_ldr:
+        hits = 0
+        for l, _ in patches:
+            base = l / np.float32(255.0)
+            hits += any(np.array_equal(img, np.rot90(b, k, axes=(0, 1))) for b in (base, base[:, ::-1]) for k in range(4))
+        assert hits == 1
