@@ -158,9 +158,10 @@ def main():
 
         def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            wino = (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
-                    and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}
-                    and K.winograd_pays(w.shape[2], w.shape[3]))
+            wino = None
+            if (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+                    and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}):
+                wino = K.winograd_path(w.shape[2], w.shape[3])
             e0.record()
             depth[0] += 1
             try:
@@ -168,7 +169,8 @@ def main():
             finally:
                 depth[0] -= 1
             e1.record()
-            label = "winograd_f2x2_3x3 (transforms + batched GEMM)" if wino else conv_variant(w, x, x2, kw.get("algo", 0))
+            label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
+                     "winograd_fused_kernel" if wino == "fused" else conv_variant(w, x, x2, kw.get("algo", 0)))
             records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
                             "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
                                                         0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),
@@ -205,9 +207,11 @@ def main():
             if not nested:
                 a = layers.setdefault(var, [0.0, 0.0, 0])
                 a[0] += fl; a[1] += sec; a[2] += 1
-            if nested or not var.startswith("winograd"):
+            if nested or not var.startswith("winograd_f2x2"):
                 a = agg.setdefault(var, [0.0, 0.0, 0])
-                a[0] += fl; a[1] += sec; a[2] += 1
+                # per KERNEL the MFMA FLOPs it executes: the fused Winograd kernel runs 16 / 36 of the layer's direct-form FLOPs
+                a[0] += fl / 2.25 if var == "winograd_fused_kernel" else fl
+                a[1] += sec; a[2] += 1
         reps = 1             # `calls` holds one pass
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[dom]
@@ -231,6 +235,8 @@ def main():
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
             "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
+            "flop_convention": "MFMA FLOPs the kernel executes (Winograd kernels: layer FLOPs / 2.25); per_layer_path holds the "
+                               "reference layers' direct-form (algorithmic) FLOPs",
             "all_conv": {"tflops": round(conv_total_flops / conv_total_sec / 1e12, 2),
                          "ms_per_step": round(conv_total_sec * 1e3, 3),
                          "gflop_per_step": round(conv_total_flops / 1e9, 1)},

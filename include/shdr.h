@@ -274,6 +274,13 @@ int shdr_mean_norm_fwd_f32(const float* r, const float* sum, float* out, int B, 
 int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, float* dr, int B,
                            int64_t n_per_sample, float eps, float target, void* stream);
 
+/* Fused Winograd F(2x2,3x3): 3x3 / stride 1 / SAME convolution with the input transform, the 16 GEMMs and the output
+ * transform in one kernel (no V / M planes in HBM).  u = shdr_winograd_filter_f32(w) [16][Cin][Cout];
+ * y = act2(affine(act1(conv + bias))).  Needs Cin % 8 == 0, Cout % 64 == 0.  Same call sites as shdr_conv2d_fwd_f32. */
+int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
+                                   const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
+                                   int act1, int act2, void* stream);
+
 /* ---- inference-tool image plumbing (test_real_refinement.py:119-155) -------------- */
 /* y[p][c] = x[p][reverse ? 2-c : c] / 255: the decoded 8-bit image as float in [0,1] (:125). */
 int shdr_u8_to_unit_f32(const uint8_t* x, float* y, int64_t npix, int reverse_channels, void* stream);

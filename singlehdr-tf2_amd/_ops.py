@@ -31,6 +31,17 @@ def winograd_pays(cin, cout):
     return cin % 32 == 0 and cout % 16 == 0 and min(cin, cout) >= 128 and cin * cout >= 32768
 
 
+def winograd_path(cin, cout):
+    """Which Winograd form a 3x3 / stride-1 layer takes (tools/wino_bench.py, batch 16 on MI355X): the one-kernel fused form
+    beats the direct kernel on every shape it accepts (+20..45 %); the three-kernel form with its 128x128-tile GEMM is still
+    ahead from 512 input channels up (220 vs 195 TFLOP/s algorithmic at 512->512)."""
+    if winograd_pays(cin, cout) and cin >= 512:
+        return "planes"
+    if cin % 8 == 0 and cout % 64 == 0 and cin >= 32:
+        return "fused"
+    return "planes" if winograd_pays(cin, cout) else None
+
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
@@ -109,9 +120,12 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
         return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
                                shift=shift, residual=residual, act2=act2, algo=algo, cout_valid=cout_valid)
     if (WINOGRAD and algo == ALGO_AUTO and x2 is None and residual is None and pad is None and cout_valid is None
-            and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)
-            and winograd_pays(w.shape[2], w.shape[3])):
-        return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
+            and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)):
+        path = winograd_path(w.shape[2], w.shape[3])
+        if path == "fused":
+            return conv2d_winograd_fused(x, winograd_filter(w), bias, act1, scale, shift, act2)
+        if path == "planes":
+            return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
     lib = _lib.load()
     x = _chk(_d(x), "x")
     w = _chk(_d(w), "w")
@@ -774,6 +788,20 @@ def winograd_filter(w):
     u = torch.empty((16, cin, cout), device=w.device, dtype=torch.float32)
     _lib.check(lib.shdr_winograd_filter_f32(_ptr(w), _ptr(u), cin, cout, _stream()), "shdr_winograd_filter_f32")
     return u
+
+
+def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):
+    """3x3 / stride 1 / SAME convolution through the ONE-kernel Winograd F(2x2,3x3) (csrc/winograd_fused.hip)"""
+    lib = _lib.load()
+    x, u = _chk(_d(x), "x"), _chk(_d(u), "u")
+    n, h, w, c = x.shape
+    cout = u.shape[2]
+    if u.shape[0] != 16 or u.shape[1] != c or c % 8 or cout % 64:
+        raise ValueError("conv2d_winograd_fused: need u [16, Cin, Cout] with Cin %% 8 == 0 and Cout %% 64 == 0")
+    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_conv2d_winograd_fused_f32(_ptr(x), _ptr(u), _ptr(_d(bias)), _ptr(_d(scale)), _ptr(_d(shift)), _ptr(y),
+                                                  n, h, w, c, cout, act1, act2, _stream()), "shdr_conv2d_winograd_fused_f32")
+    return y
 
 
 def conv2d_winograd(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):

@@ -24,6 +24,7 @@ SOURCES = {
     "bwd.hip": [],
     "finetune.hip": [],
     "winograd.hip": [],
+    "winograd_fused.hip": [],
     "frontend.hip": ["-ffp-contract=off"],
     "pool.hip": [],
     "crf.hip": [],
