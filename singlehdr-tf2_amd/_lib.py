@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshdr.so")
+LIB_PATH = os.environ.get("SHDR_LIB") or os.path.join(_HERE, "libshdr.so")     # SHDR_LIB: an alternative build (kernel experiments)
 
 c_int = ctypes.c_int
 c_i64 = ctypes.c_int64

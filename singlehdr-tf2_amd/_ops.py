@@ -33,10 +33,8 @@ def winograd_pays(cin, cout):
 
 def winograd_path(cin, cout):
     """Which Winograd form a 3x3 / stride-1 layer takes (tools/wino_bench.py, batch 16 on MI355X): the one-kernel fused form
-    beats the direct kernel on every shape it accepts (+20..45 %); the three-kernel form with its 128x128-tile GEMM is still
-    ahead from 512 input channels up (220 vs 195 TFLOP/s algorithmic at 512->512)."""
-    if winograd_pays(cin, cout) and cin >= 512:
-        return "planes"
+    beats the direct kernel (+55..75 %) and the three-kernel form (+3..150 %) on every shape it accepts; the three-kernel
+    form stays for wide layers whose Cout is not a multiple of 64."""
     if cin % 8 == 0 and cout % 64 == 0 and cin >= 32:
         return "fused"
     return "planes" if winograd_pays(cin, cout) else None

@@ -15,6 +15,8 @@
 // Algorithmic intensity vs HBM is that of the direct kernel (input read once per cout slice, output written once);
 // the MFMA count is 2.25x lower.  Replaces the same tf.keras.layers.Conv2D call sites as shdr_conv2d_fwd_f32
 // (hallucination_net.py:43-75,115-144, vgg16.py:72-83, dequantization_net.py:35-46 for the 3x3 stride-1 layers).
+#include <stdlib.h>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -253,6 +255,214 @@ __global__ __launch_bounds__(512) void winograd_fused_kernel(const WinoFusedArgs
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: no V staging.  The A operand of v_mfma_f32_16x16x4_f32 wants, per lane, V[xi][tile = lane & 15][channel = lane >> 4 ...]
+// -- exactly one lane of the one wave that owns xi.  So every lane builds its own operand values straight from the raw
+// patch in LDS (6 ds_read_b64 + 10 VALU per 16-tile group and chunk: xi = (row combination i, column combination j) needs
+// 2 patch rows x 3 patch columns), and the U slice of a wave's two xi is private to that wave.  What is left to share
+// is the raw patch: 78 KB of LDS per block instead of 139 KB -> TWO blocks (16 wavefronts) per CU, one barrier per chunk
+// that only orders the raw-patch DMA.  The epilogue runs in two passes over 32-cout halves to stay inside that LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int M2_STRIDE = 36;
+// raw patch image of v2: 16-byte slots [channel quad][patch row (pitch 20)][patch column + (tile-row parity)].  A lane's
+// ds_read_b64 then takes one slot per (tile column, tile-row parity) = 16 different slots of 16 bytes per half-wave:
+// conflict-free (the pixel-major image of v1 lands 4 lanes on every bank pair: measured LDS-bound)
+constexpr int RP2 = 20, QS2 = 10 * RP2;          // slots per patch row / per channel quad
+constexpr int RAW2_FLOATS = 7 * 256;             // 7 wave DMA instructions >= 2 * 200 slots
+constexpr int PIPE2_FLOATS = 2 * (RAW2_FLOATS + U_FLOATS);
+constexpr int EPI2_FLOATS = 16 * 32 * M2_STRIDE;
+constexpr int LDS2_BYTES = (EPI2_FLOATS > PIPE2_FLOATS ? EPI2_FLOATS : PIPE2_FLOATS) * 4;
+
+__global__ __launch_bounds__(512, 4) void winograd_fused2_kernel(const WinoFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* raw = smem;                         // [2][RAW2_FLOATS]
+  float* Us = smem + 2 * RAW2_FLOATS;        // [2][8 waves][2 xi][8 ch][64 co], column swizzled
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
+  const int pn = L / a.nblk_m;
+  int pm = L - pn * a.nblk_m;
+  const int tx = pm % a.tiles_x;
+  pm /= a.tiles_x;
+  const int ty = pm % a.tiles_y;
+  const int img = pm / a.tiles_y;
+  const int oh0 = ty * 8, ow0 = tx * 16, n0 = pn * 64;
+  const float* zero = g_wf_zero_page;
+  const int nch = a.Cin >> 3;
+  const int xi0 = 2 * wave;
+
+  // ---- DMA geometry ---------------------------------------------------------------------------------------------------
+  bool raw_ok = false;
+  unsigned raw_off = 0;
+  {
+    const int slot = wave * 64 + lane;       // waves 0..6
+    const int quad = slot / QS2, rem = slot - quad * QS2;
+    const int py = rem / RP2, px = rem - py * RP2 - ((py >> 1) & 1);
+    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+    raw_ok = wave < 7 && quad < 2 && px >= 0 && px < PW && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    if (raw_ok) raw_off = ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.Cin + 4u * quad;
+  }
+  unsigned u_off[4];                          // this wave's own two xi planes
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int Q = j * 64 + lane;
+    const int x2 = Q >> 7, ch = (Q >> 4) & 7, pq = Q & 15;
+    const int lq = pq ^ (4 * ((ch >> 1) & 3));
+    u_off[j] = ((unsigned)((xi0 + x2) * a.Cin + ch) * (unsigned)a.Cout) + (unsigned)(n0 + 4 * lq);
+  }
+  auto dma_chunk = [&](int c, int buf) {
+    const unsigned base = 8u * (unsigned)c * (unsigned)a.Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.u + (size_t)(u_off[j] + base)),
+                                       (lptr_t)(Us + buf * U_FLOATS + wave * 1024 + j * 256), 16, 0, 0);
+    if (wave < 7) {
+      const float* p = raw_ok ? a.x + (size_t)(raw_off + 8u * (unsigned)c) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(raw + buf * RAW2_FLOATS + wave * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- operand geometry -----------------------------------------------------------------------------------------------
+  const int fi = lane & 15, fg = lane >> 4;
+  const int wi = wave >> 1, jp = wave & 1;    // B^T row combination i; column pair: jp = 0 -> j in {0,1}, 1 -> {2,3}
+  // V row i = d[ra] + sr * d[rb]:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
+  const int ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
+  const int rb = wi == 3 ? 3 : (wi == 2 ? 1 : 2);
+  const float sr = wi == 1 ? 1.0f : -1.0f;
+  int a_addr[2][2];                           // [mt][row a / row b]: float offset of patch column 2*txx + jp, channels 2fg..2fg+1
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int tyy = 2 * mt + (fi >> 3), txx = fi & 7;
+    const int pa = 2 * tyy + ra, pb = 2 * tyy + rb;
+    a_addr[mt][0] = ((fg >> 1) * QS2 + pa * RP2 + 2 * txx + jp + ((pa >> 1) & 1)) * 4 + 2 * (fg & 1);
+    a_addr[mt][1] = ((fg >> 1) * QS2 + pb * RP2 + 2 * txx + jp + ((pb >> 1) & 1)) * 4 + 2 * (fg & 1);
+  }
+  int b_off[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) b_off[nt] = wave * 1024 + (2 * fg) * 64 + ((nt * 16 + fi) ^ (16 * fg));   // + x2*512 + s*64
+
+  f32x4 acc[2][2][4];
+#pragma unroll
+  for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[x2][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_chunk(0, 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const int b = c & 1;
+    // every LDS read of this chunk is issued before the next chunk's DMAs (see v1)
+    const float* rp = raw + b * RAW2_FLOATS;
+    const float* ub = Us + b * U_FLOATS;
+    float2 d[2][2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[mt][rr][k] = *reinterpret_cast<const float2*>(rp + a_addr[mt][rr] + k * 4);
+    float bq[2][2][4];
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bq[x2][s][nt] = ub[b_off[nt] + x2 * 512 + s * 64];
+    if (c + 1 < nch) dma_chunk(c + 1, b ^ 1);
+
+    float2 v[2][2];                           // [x2][mt]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float2 r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        r[k].x = d[mt][0][k].x + sr * d[mt][1][k].x;
+        r[k].y = d[mt][0][k].y + sr * d[mt][1][k].y;
+      }
+      if (jp == 0) {                          // columns 0,1,2: j=0: c0-c2, j=1: c1+c2
+        v[0][mt] = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
+        v[1][mt] = make_float2(r[1].x + r[2].x, r[1].y + r[2].y);
+      } else {                                // columns 1,2,3: j=2: c2-c1, j=3: c1-c3
+        v[0][mt] = make_float2(r[1].x - r[0].x, r[1].y - r[0].y);
+        v[1][mt] = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[x2][0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][0].x, bq[x2][0][nt], acc[x2][0][nt], 0, 0, 0);
+        acc[x2][1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][1].x, bq[x2][0][nt], acc[x2][1][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[x2][0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][0].y, bq[x2][1][nt], acc[x2][0][nt], 0, 0, 0);
+        acc[x2][1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][1].y, bq[x2][1][nt], acc[x2][1][nt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue in two 32-cout passes ---------------------------------------------------------------------------------
+  float* Ms = smem;
+  const int co = tid & 31, tg = tid >> 5;    // thread = (cout of the half, tile group); tiles tg and tg + 16
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 t = h == 0 ? acc[x2][mt][n2] : acc[x2][mt][2 + n2];
+            Ms[((xi0 + x2) * 32 + mt * 16 + 4 * fg + r) * M2_STRIDE + n2 * 16 + fi] = t[r];
+          }
+    __syncthreads();
+    const int cg = n0 + 32 * h + co;
+    const float bv = a.bias ? a.bias[cg] : 0.0f;
+    const float sc = a.scale ? a.scale[cg] : 1.0f;
+    const float sh = a.scale ? a.shift[cg] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int tile = tg + 16 * k, tyy = tile >> 3, txx = tile & 7;
+      const float* mp = Ms + tile * M2_STRIDE + co;
+      float s[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m0 = mp[(0 * 4 + j) * 32 * M2_STRIDE], m1 = mp[(1 * 4 + j) * 32 * M2_STRIDE];
+        const float m2 = mp[(2 * 4 + j) * 32 * M2_STRIDE], m3 = mp[(3 * 4 + j) * 32 * M2_STRIDE];
+        s[0][j] = m0 + m1 + m2;
+        s[1][j] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oh = oh0 + 2 * tyy + i;
+        if (oh >= a.H) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ow = ow0 + 2 * txx + j;
+          if (ow >= a.W) continue;
+          float v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
+          v = shdr::act_apply(v + bv, a.act1);
+          if (a.scale) v = v * sc + sh;
+          v = shdr::act_apply(v, a.act2);
+          a.y[((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + cg] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
@@ -276,12 +486,21 @@ extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, co
   const long nblk = (long)a.nblk_m * a.nblk_n;
   SHDR_REQUIRE(nblk > 0 && nblk <= 0x7fffffffL, SHDR_E_SHAPE, "winograd_fused: grid of %ld blocks", nblk);
   static bool attr_done = false;
+  static int variant = 2;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_fused2_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const char* v = getenv("SHDR_WINOGRAD_FUSED_VARIANT");     // 1: V staged through LDS, 2 (default): operands built per lane
+    if (v && v[0] == '1') variant = 1;
     attr_done = true;
   }
-  hipLaunchKernelGGL(winograd_fused_kernel, dim3((unsigned)nblk), dim3(512), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+  if (variant == 1)
+    hipLaunchKernelGGL(winograd_fused_kernel, dim3((unsigned)nblk), dim3(512), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(winograd_fused2_kernel, dim3((unsigned)nblk), dim3(512), LDS2_BYTES, reinterpret_cast<hipStream_t>(stream), a);
   return shdr::check_launch("winograd_fused_kernel");
 }
