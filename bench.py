@@ -224,8 +224,11 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 tk = json.load(f)["kernels"]
-            key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
-            hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
+            if dom.startswith("conv_mfma"):
+                key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
+                hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
+            else:
+                hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(dom)]
             traffic = hits[0] if hits else None
         except (OSError, KeyError, ValueError):
             pass

@@ -291,3 +291,32 @@ def test_conv2d_winograd_parity(shdr, shape):
     y0 = K.conv2d_winograd(dev(x), u)
     assert rel_err(host(y0), oracle_conv(x, wt)) <= TOL
     assert rel_err(host(y0), host(K.conv2d(dev(x), dev(wt)))) <= 5e-6     # vs the direct MFMA kernel
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 13, 18, 32, 64), (1, 8, 16, 256, 64), (3, 6, 4, 8, 64),
+                                   (1, 21, 37, 72, 192), (2, 32, 32, 128, 64)])
+def test_conv2d_winograd_fused_parity(shdr, shape):
+    """One-kernel Winograd F(2x2,3x3) (operands built per lane from the raw patch in LDS) vs the float64 oracle: ragged
+    tiles (H % 8, W % 16 != 0, image smaller than one block tile), Cin a multiple of 8 only, the fused epilogue."""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    u = K.winograd_filter(dev(wt))
+    ref = oracle_conv(x, wt, b, act1=2, scale=sc, shift=sh, act2=1)
+    y = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    y0 = K.conv2d_winograd_fused(dev(x), u)
+    assert rel_err(host(y0), oracle_conv(x, wt)) <= TOL
+    K.WINOGRAD, saved = False, K.WINOGRAD
+    try:
+        assert rel_err(host(y0), host(K.conv2d(dev(x), dev(wt)))) <= 5e-6     # vs the direct MFMA kernel
+    finally:
+        K.WINOGRAD = saved
+    assert K.winograd_path(cin, cout) == ("fused" if cin >= 32 else None)      # ... and this is what conv2d() dispatches to
+    if cin >= 32:
+        assert torch.equal(K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU), y)
+    with pytest.raises(ValueError, match="Cout"):
+        K.conv2d_winograd_fused(dev(x), K.winograd_filter(dev(np.ascontiguousarray(wt[..., :48]))))
