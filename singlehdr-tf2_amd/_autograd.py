@@ -38,10 +38,11 @@ def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
     if cin_pad or cout_pad:
         wt = F.pad(wt, (0, cout_pad, 0, cin_pad))
         dz = K.pad_channels(dz, cout_real + cin_pad)
+    cv = c_count if cout_pad else None                # None: an unpadded filter may take the Winograd kernels
     if stride == 1:
-        return K.conv2d(dz, wt, cout_valid=c_count)
+        return K.conv2d(dz, wt, cout_valid=cv)
     if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
-        return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=c_count), x_shape)
+        return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=cv), x_shape)
     if stride == 2:
         # general stride 2 (the 7x7/2 first conv of the Linearization-Net in the fine-tuning chain):
         # zero-insert dz to the input grid, then a stride-1 conv with the flipped filter and the
