@@ -274,6 +274,12 @@ int shdr_mean_norm_fwd_f32(const float* r, const float* sum, float* out, int B, 
 int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, float* dr, int B,
                            int64_t n_per_sample, float eps, float target, void* stream);
 
+/* Backward of  y = act(conv + bias):  dz = dy * act'(y) (from the activation OUTPUT) and db[c] += sum_p dz[p][c] in one
+ * pass (the caller zeroes db).  act == SHDR_ACT_NONE: dz is not written (dz = dy) and only db is accumulated.
+ * C / 4 must be a power of two <= 256.  Replaces the act_bwd + bias_grad pair of GradientTape.gradient through
+ * tf.nn.leaky_relu / relu(conv(x) + b) (dequantization_net.py:13-14, hallucination_net.py:48-52). */
+int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, int64_t npix, int C, int act, void* stream);
+
 /* Fused Winograd F(2x2,3x3): 3x3 / stride 1 / SAME convolution with the input transform, the 16 GEMMs and the output
  * transform in one kernel (no V / M planes in HBM).  u = shdr_winograd_filter_f32(w) [16][Cin][Cout];
  * y = act2(affine(act1(conv + bias))).  Needs Cin % 8 == 0, Cout % 64 == 0.  Same call sites as shdr_conv2d_fwd_f32. */

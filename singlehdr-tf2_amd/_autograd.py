@@ -82,17 +82,18 @@ class Conv2dFn(torch.autograd.Function):
         x, x2, w, y = ctx.saved_tensors
         stride, x2_scale, act1, has_bias = ctx.meta
         dy = _c(dy)
-        dz = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
         dx = dx2 = dw = db = None
+        if need_b and has_bias:
+            dz, db = K.act_bwd_bias(dy, y, act1)         # one pass: activation backward + bias gradient
+        else:
+            dz = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
         c1 = x.shape[3]
         if need_w:
             kh, kw, cin, cout_gemm = w.shape
             dw = K.conv2d_wgrad(x, x2, dz, (kh, kw, cin, dz.shape[3]), stride, x2_scale)
             if dz.shape[3] != cout_gemm:
                 dw = F.pad(dw, (0, cout_gemm - dz.shape[3]))
-        if need_b and has_bias:
-            db = K.bias_grad(dz)
         if need_x:
             dx = _dgrad(dz, w, 0, c1, 1.0, stride, x.shape)
         if need_x2 and x2 is not None:

@@ -466,6 +466,27 @@ def bias_grad(dz):
     return db
 
 
+def act_bwd_bias(dy, y, act):
+    """(dz, db) of y = act(z + bias): dz = dy * act'(y), db = sum over pixels of dz -- one fused pass when the channel
+    count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise"""
+    dy = _chk(_d(dy), "dy")
+    c = dy.shape[-1]
+    q = c // 4
+    if c % 4 or q > 256 or q & (q - 1):
+        dz = act_bwd(dy, y, act) if act != ACT_NONE else dy
+        return dz, bias_grad(dz)
+    lib = _lib.load()
+    db = torch.zeros(c, device=dy.device, dtype=torch.float32)
+    if act == ACT_NONE:
+        dz, yp, zp = dy, None, None
+    else:
+        y = _chk(_d(y), "y")
+        dz = torch.empty_like(dy)
+        yp, zp = _ptr(y), _ptr(dz)
+    _lib.check(lib.shdr_act_bwd_bias_f32(_ptr(dy), yp, zp, _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f32")
+    return dz, db
+
+
 def act_bwd(dy, y, act):
     lib = _lib.load()
     dy, y = _chk(_d(dy), "dy"), _chk(_d(y), "y")

@@ -47,6 +47,50 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// Fused dz = dy * act'(y) and db[c] += sum_p dz[p][c]: one pass over dy / y instead of act_bwd + bias_grad (three tensor
+// passes instead of four, float4 accesses).  C / 4 is a power of two <= 256, so a thread's channel quad is fixed over its
+// grid-stride loop and the four sums stay in registers; one LDS tree + one atomic per block and channel.
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ dz, float* __restrict__ db, long nquads,
+                                                           int Q, int act) {
+  __shared__ float4 part[256];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nquads; e += (long)gridDim.x * 256) {
+    const float4 g = *reinterpret_cast<const float4*>(dy + 4 * e);
+    float4 d = g;
+    if (act != SHDR_ACT_NONE) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + 4 * e);
+      if (act == SHDR_ACT_RELU) {
+        d.x = yv.x > 0.f ? g.x : 0.f; d.y = yv.y > 0.f ? g.y : 0.f; d.z = yv.z > 0.f ? g.z : 0.f; d.w = yv.w > 0.f ? g.w : 0.f;
+      } else if (act == SHDR_ACT_LRELU) {
+        d.x = yv.x > 0.f ? g.x : 0.1f * g.x; d.y = yv.y > 0.f ? g.y : 0.1f * g.y;
+        d.z = yv.z > 0.f ? g.z : 0.1f * g.z; d.w = yv.w > 0.f ? g.w : 0.1f * g.w;
+      } else {
+        d.x = g.x * (1.0f - yv.x * yv.x); d.y = g.y * (1.0f - yv.y * yv.y);
+        d.z = g.z * (1.0f - yv.z * yv.z); d.w = g.w * (1.0f - yv.w * yv.w);
+      }
+      *reinterpret_cast<float4*>(dz + 4 * e) = d;
+    }
+    s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= Q; off >>= 1) {            // threads t and t + k*Q hold the same channel quad
+    if ((int)threadIdx.x < off) {
+      const float4 o = part[threadIdx.x + off];
+      float4 m = part[threadIdx.x];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      part[threadIdx.x] = m;
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < Q) {
+    const float4 m = part[threadIdx.x];
+    float* o = db + 4 * threadIdx.x;
+    atomicAdd(o, m.x); atomicAdd(o + 1, m.y); atomicAdd(o + 2, m.z); atomicAdd(o + 3, m.w);
+  }
+}
+
 // clip backward: gradient passes inside the closed interval [lo, hi] (tf.clip_by_value)
 __global__ __launch_bounds__(256) void clip_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        float* __restrict__ dx, long n, float lo, float hi) {
@@ -593,6 +637,24 @@ extern "C" int shdr_act_bwd_f32(const float* dy, const float* y, float* dx, int6
   SHDR_REQUIRE(n > 0 && act >= 0 && act <= 3, SHDR_E_SHAPE, "act_bwd: bad arguments");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, S(stream), dy, y, dx, (long)n, act);
   return shdr::check_launch("act_bwd");
+}
+extern "C" int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, int64_t npix, int C, int act,
+                                     void* stream) {
+  SHDR_REQUIRE(dy && db, SHDR_E_NULL, "act_bwd_bias: null pointer");
+  SHDR_REQUIRE(act == SHDR_ACT_NONE || (y && dz), SHDR_E_NULL, "act_bwd_bias: y and dz are needed with an activation");
+  SHDR_REQUIRE(npix > 0 && act >= 0 && act <= 3, SHDR_E_SHAPE, "act_bwd_bias: bad arguments");
+  const int Q = C / 4;
+  SHDR_REQUIRE(C % 4 == 0 && Q >= 1 && Q <= 256 && (Q & (Q - 1)) == 0, SHDR_E_SHAPE,
+               "act_bwd_bias: C / 4 must be a power of two <= 256 (got C = %d)", C);
+  SHDR_REQUIRE(shdr::aligned16(dy) && (!y || shdr::aligned16(y)) && (!dz || shdr::aligned16(dz)), SHDR_E_ALIGN,
+               "act_bwd_bias: tensors must be 16-byte aligned");
+  const long nquads = (long)npix * Q;
+  // <= 512 blocks: every block ends with one atomic per channel on the SAME C addresses (2048 blocks measured slower than
+  // the unfused pair)
+  int grid = shdr::stream_grid(nquads);
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), 0, S(stream), dy, y, dz, db, nquads, Q, act);
+  return shdr::check_launch("act_bwd_bias");
 }
 extern "C" int shdr_clip_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, float lo, float hi, void* stream) {
   SHDR_REQUIRE(dy && x && dx, SHDR_E_NULL, "clip_bwd: null pointer");

@@ -346,3 +346,18 @@ def test_residual_blocks_exact_on_shared_inputs(shdr):
         for nm, t, tr in blk.named_weights():
             if tr:
                 assert rel_err(host(t.grad), tp[pre + nm].grad.numpy()) <= 1e-5, pre + nm
+
+
+@pytest.mark.parametrize("c", [16, 64, 512, 1024, 12, 3])
+def test_fused_activation_backward_and_bias_gradient(shdr, c):
+    """act_bwd_bias = act_bwd followed by bias_grad (the fused kernel for C/4 a power of two, the pair otherwise)"""
+    K = shdr._ops
+    g = torch.Generator().manual_seed(c)
+    dy = torch.randn((3, 9, 11, c), generator=g).cuda()
+    y = torch.randn((3, 9, 11, c), generator=g).cuda()
+    for act in (K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K.ACT_TANH):
+        dz, db = K.act_bwd_bias(dy, y, act)
+        want = K.act_bwd(dy, y, act) if act != K.ACT_NONE else dy
+        assert torch.equal(dz, want)
+        ref = want.double().sum(dim=(0, 1, 2))
+        assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max() + 1)
