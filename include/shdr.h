@@ -280,8 +280,11 @@ int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, 
  * tf.nn.leaky_relu / relu(conv(x) + b) (dequantization_net.py:13-14, hallucination_net.py:48-52). */
 int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, int64_t npix, int C, int act, void* stream);
 
+/* U = G g G^T of a 3x3 HWIO filter in the operand order of the fused kernel (one coalesced float4 per lane, chunk and
+ * operand group; layout documented at winograd_filter_packed_kernel).  up: 16*Cin*Cout floats. */
+int shdr_winograd_filter_packed_f32(const float* w, float* up, int Cin, int Cout, void* stream);
 /* Fused Winograd F(2x2,3x3): 3x3 / stride 1 / SAME convolution with the input transform, the 16 GEMMs and the output
- * transform in one kernel (no V / M planes in HBM).  u = shdr_winograd_filter_f32(w) [16][Cin][Cout];
+ * transform in one kernel (no V / M planes in HBM).  u = shdr_winograd_filter_packed_f32(w);
  * y = act2(affine(act1(conv + bias))).  Needs Cin % 8 == 0, Cout % 64 == 0.  Same call sites as shdr_conv2d_fwd_f32. */
 int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
                                    const float* shift, float* y, int N, int H, int W, int Cin, int Cout,

@@ -121,7 +121,7 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
             and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)):
         path = winograd_path(w.shape[2], w.shape[3])
         if path == "fused":
-            return conv2d_winograd_fused(x, winograd_filter(w), bias, act1, scale, shift, act2)
+            return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, scale, shift, act2)
         if path == "planes":
             return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
     lib = _lib.load()
@@ -809,8 +809,22 @@ def winograd_filter(w):
     return u
 
 
+def winograd_filter_packed(w):
+    """U = G g G^T of a 3x3 HWIO filter in the operand order of the fused kernel: a [16, Cin, Cout]-sized tensor whose
+    MEMORY is [Cout/64][8 waves][Cin/8][4][64 lanes][4] (see winograd_filter_packed_kernel)"""
+    lib = _lib.load()
+    w = _chk(_d(w), "w")
+    kh, kw, cin, cout = w.shape
+    if (kh, kw) != (3, 3) or cin % 8 or cout % 64:
+        raise ValueError("winograd_filter_packed: 3x3 filters with Cin %% 8 == 0 and Cout %% 64 == 0 only")
+    u = torch.empty((16, cin, cout), device=w.device, dtype=torch.float32)
+    _lib.check(lib.shdr_winograd_filter_packed_f32(_ptr(w), _ptr(u), cin, cout, _stream()), "shdr_winograd_filter_packed_f32")
+    return u
+
+
 def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):
-    """3x3 / stride 1 / SAME convolution through the ONE-kernel Winograd F(2x2,3x3) (csrc/winograd_fused.hip)"""
+    """3x3 / stride 1 / SAME convolution through the ONE-kernel Winograd F(2x2,3x3) (csrc/winograd_fused.hip);
+    `u` from winograd_filter_packed()"""
     lib = _lib.load()
     x, u = _chk(_d(x), "x"), _chk(_d(u), "u")
     n, h, w, c = x.shape

@@ -44,6 +44,45 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __res
   }
 }
 
+// The same U = G g G^T, stored in the operand order of winograd_fused_kernel (winograd_fused.hip): for cout slice pn, wave w8
+// (transform positions 2*w8, 2*w8+1), 8-channel chunk c, the 16 B-operand values of a lane are four float4
+//   up[((((pn*8 + w8)*nch + c)*4 + j)*64 + lane)*4 + nt],   j = 2*(xi & 1) + (ci & 1),  lane = 16*((ci & 7) >> 1) + (co & 15),
+//   nt = (co & 63) >> 4  -- one fully coalesced 1 KiB global_load_dwordx4 per (chunk, j) and wave, straight into VGPRs.
+__global__ __launch_bounds__(256) void winograd_filter_packed_kernel(const float* __restrict__ w, float* __restrict__ up, int Cin,
+                                                                     int Cout) {
+  const long cc = (long)Cin * Cout;
+  const int nch = Cin >> 3;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < cc; e += (long)gridDim.x * 256) {
+    const int co = (int)(e % Cout), ci = (int)(e / Cout);
+    float g[3][3], t[4][3], u[16];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = w[(a * 3 + b) * cc + e];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = g[0][b];
+      t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i * 4 + 0] = t[i][0];
+      u[i * 4 + 1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      u[i * 4 + 2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      u[i * 4 + 3] = t[i][2];
+    }
+    const int pn = co >> 6, nt = (co & 63) >> 4, lane = 16 * ((ci & 7) >> 1) + (co & 15);
+    const int c = ci >> 3, s = ci & 1;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      const int j = 2 * (xi & 1) + s;
+      up[((((long)(pn * 8 + (xi >> 1)) * nch + c) * 4 + j) * 64 + lane) * 4 + nt] = u[xi];
+    }
+  }
+}
+
 // V[xi][t][c] = (B^T d B)[xi],  d = 4x4 input patch at (2*th-1, 2*tw-1), zero outside the image
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N, int H,
@@ -158,6 +197,14 @@ extern "C" int shdr_winograd_filter_f32(const float* w, float* u, int Cin, int C
   const long cc = (long)Cin * Cout;
   hipLaunchKernelGGL(winograd_filter_kernel, dim3(shdr::stream_grid(cc)), dim3(256), 0, S(stream), w, u, cc);
   return shdr::check_launch("winograd_filter");
+}
+
+extern "C" int shdr_winograd_filter_packed_f32(const float* w, float* up, int Cin, int Cout, void* stream) {
+  SHDR_REQUIRE(w && up, SHDR_E_NULL, "winograd_filter_packed: null pointer");
+  SHDR_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 64 == 0, SHDR_E_SHAPE,
+               "winograd_filter_packed: need Cin %% 8 == 0 and Cout %% 64 == 0");
+  hipLaunchKernelGGL(winograd_filter_packed_kernel, dim3(shdr::stream_grid((long)Cin * Cout)), dim3(256), 0, S(stream), w, up, Cin, Cout);
+  return shdr::check_launch("winograd_filter_packed");
 }
 
 extern "C" int64_t shdr_winograd_tiles(int N, int H, int W) {

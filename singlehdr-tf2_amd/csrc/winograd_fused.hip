@@ -4,9 +4,11 @@
 //   block  = 8 x 16 output pixels (32 Winograd tiles) x 64 output channels x all 16 transform positions xi,
 //            512 threads = 8 wavefronts, two blocks per CU; wave w owns xi = {2w, 2w+1}: 2 x (32 tiles x 64 couts) fp32
 //            accumulators = 64 registers.
-//   K loop = 8 input channels per chunk, double buffered.  Per chunk and block:
-//            raw patch  10 x 18 pixels x 8 ch   HBM/L2 -> LDS by global_load_lds (zero page outside the image)
-//            U slices   16 x 8 x 64             L2 -> LDS by global_load_lds; every wave fetches the two xi planes it owns
+//   K loop = 8 input channels per chunk.  Per chunk and block:
+//            raw patch  10 x 18 pixels x 8 ch   HBM/L2 -> LDS by global_load_lds (zero page outside the image), double buffered
+//            filter     16 x 8 x 64             L2 -> VGPRs: the 16 B-operand values of a lane are four coalesced float4 loads
+//                                               from the packed layout of winograd_filter_packed_kernel -- no LDS, no DMA; a
+//                                               register group is refilled for chunk c+1 right after the MFMAs that read it
 //            256 x v_mfma_f32_16x16x4_f32       A = V (row = tile), B = U (col = cout)
 //   There is NO V staging: the A operand wants V[xi][tile = lane & 15][channel pair = lane >> 4] in exactly one lane of
 //   the one wave that owns xi, so every lane builds its own operand values straight from the raw patch in LDS --
@@ -38,7 +40,7 @@ __device__ __attribute__((aligned(16))) float g_wf_zero_page[4] = {0.f, 0.f, 0.f
 
 struct WinoFusedArgs {
   const float* x;      // [N,H,W,Cin]
-  const float* u;      // [16][Cin][Cout]  (winograd_filter_kernel)
+  const float* u;      // packed U (winograd_filter_packed_kernel)
   const float* bias;
   const float* scale;
   const float* shift;
@@ -50,7 +52,6 @@ struct WinoFusedArgs {
 
 constexpr int PW = 18;                           // raw patch columns (16 + 2)
 constexpr int RP2 = 20;                          // slots per patch row
-constexpr int U_FLOATS = 16 * 8 * 64;
 constexpr int M2_STRIDE = 36;                    // 32 couts + 4: the 4 row groups of an accumulator tile hit disjoint banks
 
 // R = block height in units of 8 output rows: R = 1 -> 8 x 16 pixels, 32 tiles, 64 accumulator registers, two blocks per CU;
@@ -61,9 +62,10 @@ struct WF {
   static constexpr int MT = 2 * R;                         // 16-tile groups
   static constexpr int PROWS = 8 * R + 2;                  // raw patch rows
   static constexpr int QS = PROWS * RP2;                   // slots per channel quad
-  static constexpr int RAW_INSTR = (2 * QS + 63) / 64;     // wave DMA instructions per raw patch
+  static constexpr int RAW_INSTR = ((2 * QS + 63) / 64 + 7) / 8 * 8;   // wave DMA instructions per raw patch, the same
+                                                                       // number for every wave (uniform vmcnt)
   static constexpr int RAW_FLOATS = RAW_INSTR * 256;
-  static constexpr int PIPE_FLOATS = 2 * (RAW_FLOATS + U_FLOATS);
+  static constexpr int PIPE_FLOATS = 2 * RAW_FLOATS;
   static constexpr int EPI_FLOATS = 16 * 32 * R * M2_STRIDE;
   static constexpr int LDS_BYTES = (EPI_FLOATS > PIPE_FLOATS ? EPI_FLOATS : PIPE_FLOATS) * 4;
 };
@@ -79,7 +81,6 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   constexpr int MT = G::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;                         // [2][RAW_FLOATS]
-  float* Us = smem + 2 * G::RAW_FLOATS;      // [2][8 waves][2 xi][8 ch][64 co], column swizzled
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,26 +109,14 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     raw_ok[j] = quad < 2 && px >= 0 && px < PW && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     raw_off[j] = raw_ok[j] ? ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.Cin + 4u * quad : 0u;
   }
-  unsigned u_off[4];                          // this wave's own two xi planes
+  // B operands: this lane's 16 filter values of a chunk = four float4 at up[(c*4 + j)*256], j = 2*x2 + s, .xyzw = nt 0..3
+  const float* up = a.u + ((size_t)(pn * 8 + wave) * nch * 256 + lane) * 4;
+  auto dma_raw = [&](int c, int buf) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int Q = j * 64 + lane;
-    const int x2 = Q >> 7, ch = (Q >> 4) & 7, pq = Q & 15;
-    const int lq = pq ^ (4 * ((ch >> 1) & 3));
-    u_off[j] = ((unsigned)((xi0 + x2) * a.Cin + ch) * (unsigned)a.Cout) + (unsigned)(n0 + 4 * lq);
-  }
-  auto dma_chunk = [&](int c, int buf) {
-    const unsigned base = 8u * (unsigned)c * (unsigned)a.Cout;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.u + (size_t)(u_off[j] + base)),
-                                       (lptr_t)(Us + buf * U_FLOATS + wave * 1024 + j * 256), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < RJ; ++j)
-      if (wave + 8 * j < G::RAW_INSTR) {
-        const float* p = raw_ok[j] ? a.x + (size_t)(raw_off[j] + 8u * (unsigned)c) : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(raw + buf * G::RAW_FLOATS + (wave + 8 * j) * 256), 16, 0, 0);
-      }
+    for (int j = 0; j < RJ; ++j) {
+      const float* p = raw_ok[j] ? a.x + (size_t)(raw_off[j] + 8u * (unsigned)c) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(raw + buf * G::RAW_FLOATS + (wave + 8 * j) * 256), 16, 0, 0);
+    }
   };
 
   // ---- operand geometry -----------------------------------------------------------------------------------------------
@@ -145,10 +134,6 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     a_addr[mt][0] = ((fg >> 1) * G::QS + pa * RP2 + 2 * txx + jp + ((pa >> 1) & 1)) * 4 + 2 * (fg & 1);
     a_addr[mt][1] = ((fg >> 1) * G::QS + pb * RP2 + 2 * txx + jp + ((pb >> 1) & 1)) * 4 + 2 * (fg & 1);
   }
-  int b_off[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) b_off[nt] = wave * 1024 + (2 * fg) * 64 + ((nt * 16 + fi) ^ (16 * fg));   // + x2*512 + s*64
-
   f32x4 acc[2][MT][4];
 #pragma unroll
   for (int x2 = 0; x2 < 2; ++x2)
@@ -157,14 +142,19 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[x2][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  dma_chunk(0, 0);
+  // s_waitcnt vmcnt(4), everything else unconstrained: the raw-patch DMA of the next chunk is older than the four filter loads
+  // issued after it, so "at most 4 outstanding" = "the DMA has landed" while the filter loads stay in flight across the barrier
+  constexpr int WAIT_VM4 = 0x0F74;
+  float4 bq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const float4*>(up + j * 256);
+  dma_raw(0, 0);
   __syncthreads();
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
     const int b = c & 1;
-    // every LDS read of this chunk is issued before the next chunk's DMAs (see the header)
+    // every LDS read of this chunk is issued before the next chunk's DMA (see the header)
     const float* rp = raw + b * G::RAW_FLOATS;
-    const float* ub = Us + b * U_FLOATS;
     float2 d[MT][2][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -172,13 +162,9 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
       for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int k = 0; k < 3; ++k) d[mt][rr][k] = *reinterpret_cast<const float2*>(rp + a_addr[mt][rr] + k * 4);
-    float bq[2][2][4];
-#pragma unroll
-    for (int x2 = 0; x2 < 2; ++x2)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bq[x2][s][nt] = ub[b_off[nt] + x2 * 512 + s * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    dma_raw(c + 1 < nch ? c + 1 : c, b ^ 1);      // unconditional (the last chunk refetches itself): a uniform vmcnt
+    __builtin_amdgcn_sched_barrier(0);
     float2 v[2][MT];                          // [x2][mt]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -196,28 +182,34 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
         v[1][mt] = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
       }
     }
+    const float* un = up + (size_t)(c + 1 < nch ? c + 1 : c) * 1024;       // next chunk's operands (the last chunk reloads itself)
+    // the filter registers were loaded BEFORE this chunk's raw DMA(s): "at most RJ outstanding" = "they have arrived", and
+    // the DMA stays in flight under the MFMAs (left alone, the compiler waits for vmcnt(0) here)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | RJ);
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2) {
+      const float b0[4] = {bq[2 * x2].x, bq[2 * x2].y, bq[2 * x2].z, bq[2 * x2].w};
+      const float b1[4] = {bq[2 * x2 + 1].x, bq[2 * x2 + 1].y, bq[2 * x2 + 1].z, bq[2 * x2 + 1].w};
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].x, bq[x2][0][nt], acc[x2][mt][nt], 0, 0, 0);
+          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].x, b0[nt], acc[x2][mt][nt], 0, 0, 0);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].y, bq[x2][1][nt], acc[x2][mt][nt], 0, 0, 0);
+          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].y, b1[nt], acc[x2][mt][nt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      if (x2 == 0) {
-        // the DMAs of chunk c+1 go out behind the first half of the MFMAs (all LDS reads are already issued)
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) dma_chunk(c + 1, b ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      // the MFMAs above have read their B registers: refill them for the next chunk straight from L2 (no LDS, no DMA)
+      __builtin_amdgcn_sched_barrier(0);
+      bq[2 * x2] = *reinterpret_cast<const float4*>(un + (2 * x2) * 256);
+      bq[2 * x2 + 1] = *reinterpret_cast<const float4*>(un + (2 * x2 + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(WAIT_VM4);
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue in two 32-cout passes ---------------------------------------------------------------------------------

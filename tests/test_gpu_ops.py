@@ -304,7 +304,7 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
     x = f32(rng.normal(size=(n, h, w, cin)))
     wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
     b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
-    u = K.winograd_filter(dev(wt))
+    u = K.winograd_filter_packed(dev(wt))
     ref = oracle_conv(x, wt, b, act1=2, scale=sc, shift=sh, act2=1)
     y = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
     assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
@@ -319,4 +319,4 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
     if cin >= 32:
         assert torch.equal(K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU), y)
     with pytest.raises(ValueError, match="Cout"):
-        K.conv2d_winograd_fused(dev(x), K.winograd_filter(dev(np.ascontiguousarray(wt[..., :48]))))
+        K.winograd_filter_packed(dev(np.ascontiguousarray(wt[..., :48])))

@@ -7,7 +7,7 @@ K = importlib.import_module("singlehdr-tf2_amd")._ops
 hw, cin, cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 x = torch.randn(N, hw, hw, cin, device="cuda"); w = torch.randn(3, 3, cin, cout, device="cuda") * 0.02
-u = K.winograd_filter(w)
+u = K.winograd_filter_packed(w)
 for _ in range(3): K.conv2d_winograd_fused(x, u)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
