@@ -65,7 +65,7 @@ struct WF {
   static constexpr int RAW_INSTR = ((2 * QS + 63) / 64 + 7) / 8 * 8;   // wave DMA instructions per raw patch, the same
                                                                        // number for every wave (uniform vmcnt)
   static constexpr int RAW_FLOATS = RAW_INSTR * 256;
-  static constexpr int PIPE_FLOATS = 2 * RAW_FLOATS;
+  static constexpr int PIPE_FLOATS = 4 * RAW_FLOATS;       // four raw-patch buffers: chunk c+1 is read while c+3 is in flight
   static constexpr int EPI_FLOATS = 16 * 32 * R * M2_STRIDE;
   static constexpr int LDS_BYTES = (EPI_FLOATS > PIPE_FLOATS ? EPI_FLOATS : PIPE_FLOATS) * 4;
 };
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   using G = WF<R>;
   constexpr int MT = G::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw = smem;                         // [2][RAW_FLOATS]
+  float* raw = smem;                         // [4][RAW_FLOATS]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,30 +142,33 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[x2][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // s_waitcnt vmcnt(4), everything else unconstrained: the raw-patch DMA of the next chunk is older than the four filter loads
-  // issued after it, so "at most 4 outstanding" = "the DMA has landed" while the filter loads stay in flight across the barrier
-  constexpr int WAIT_VM4 = 0x0F74;
+  // Software pipeline over the 8-channel chunks (raw patch in 4 LDS buffers, filter operands and V in registers):
+  //   iteration c:  LDS reads of raw(c+1) -> issue DMA raw(c+3) -> MFMAs of chunk c (operands v(c), bq = U(c), both already in
+  //                 registers; each bq half is refilled with U(c+1) right after the MFMAs that read it) -> V(c+1) from the
+  //                 values read at the top (their LDS latency sat under the MFMAs) -> barrier.
+  // Every LDS read precedes the DMA issue of its iteration (see the header).  Counted waits: "s_waitcnt vmcnt(RJ)" before the
+  // MFMAs = everything but this iteration's RJ raw DMAs has arrived (the filter registers AND raw(c+2), so the barrier at the
+  // end needs no wait of its own and the DMA of raw(c+3) plus the 4 filter loads stay in flight across it).
   float4 bq[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const float4*>(up + j * 256);
   dma_raw(0, 0);
+  dma_raw(nch > 1 ? 1 : 0, 1);
+  dma_raw(nch > 2 ? 2 : nch - 1, 2);
   __syncthreads();
-#pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
-    const int b = c & 1;
-    // every LDS read of this chunk is issued before the next chunk's DMA (see the header)
-    const float* rp = raw + b * G::RAW_FLOATS;
-    float2 d[MT][2][3];
+
+  float2 d[MT][2][3];
+  float2 v[2][MT];                            // [x2][mt]
+  auto read_patch = [&](int buf) {
+    const float* rp = raw + buf * G::RAW_FLOATS;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int k = 0; k < 3; ++k) d[mt][rr][k] = *reinterpret_cast<const float2*>(rp + a_addr[mt][rr] + k * 4);
-    __builtin_amdgcn_sched_barrier(0);
-    dma_raw(c + 1 < nch ? c + 1 : c, b ^ 1);      // unconditional (the last chunk refetches itself): a uniform vmcnt
-    __builtin_amdgcn_sched_barrier(0);
-    float2 v[2][MT];                          // [x2][mt]
+  };
+  auto transform = [&]() {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       float2 r[3];
@@ -182,9 +185,16 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
         v[1][mt] = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
       }
     }
+  };
+  read_patch(0);
+  transform();
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    read_patch((c + 1) & 3);                  // raw(c+1): landed and barrier-ordered one iteration ago (unused after the last chunk)
+    __builtin_amdgcn_sched_barrier(0);
+    dma_raw(c + 3 < nch ? c + 3 : nch - 1, (c + 3) & 3);      // unconditional: a uniform vmcnt
+    __builtin_amdgcn_sched_barrier(0);
     const float* un = up + (size_t)(c + 1 < nch ? c + 1 : c) * 1024;       // next chunk's operands (the last chunk reloads itself)
-    // the filter registers were loaded BEFORE this chunk's raw DMA(s): "at most RJ outstanding" = "they have arrived", and
-    // the DMA stays in flight under the MFMAs (left alone, the compiler waits for vmcnt(0) here)
     __builtin_amdgcn_s_waitcnt(0x0F70 | RJ);
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2) {
@@ -208,9 +218,11 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
       bq[2 * x2 + 1] = *reinterpret_cast<const float4*>(un + (2 * x2 + 1) * 256);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_s_waitcnt(WAIT_VM4);
+    transform();                              // V(c+1)
     __builtin_amdgcn_s_barrier();
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // drain the tail DMA / loads before the pipeline buffers become the M overlay
+  __syncthreads();
 
   // ---- epilogue in two 32-cout passes ---------------------------------------------------------------------------------
   float* Ms = smem;
