@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-size", type=int, default=256)
     ap.add_argument("--single-stream", action="store_true", help="joint step: run deq / lin / hal on one stream")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one card)")
     ap.add_argument("--finetune-steps", type=int, default=2, help="timed fine-tuning steps per precision (0 = skip that leg)")
     ap.add_argument("--finetune-batch", type=int, default=4)       # finetune_real_dataset.py:25
     ap.add_argument("--finetune-size", type=int, default=1024)
@@ -94,11 +95,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the hot path)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev                 # one rank per GPU; (rehearsals with --backend gloo may share a card)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":                # RCCL over xGMI: the production path
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     pkg = importlib.import_module("singlehdr-tf2_amd")
