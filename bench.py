@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-refinement", action="store_true", help="skip the extra inference leg with the Refinement-Net")
     ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
     ap.add_argument("--streams", type=int, default=2, help="inference: batch slices run on this many HIP streams")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one HIP graph (small-batch latency)")
@@ -155,6 +156,29 @@ def main():
                    "per_gpu_batch": args.batch, "hip_streams_per_gpu": args.streams,
                    "parallelism": "batch-sharded x%d, no collective" % n_gpus},
     }
+
+    # ---- the same inference with the Refinement-Net appended ("report with and without") ----------
+    if not args.no_refinement:
+        torch.manual_seed(4321)
+        ref_net = pkg.refinement_net.model()
+        run_ref = pkg.pipeline.Inference(deq, lin, hal, ref_net, streams=args.streams)
+        for _ in range(2):
+            out_ref = run_ref(ldr)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_ref = run_ref(ldr)
+        barrier()
+        rdt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([rdt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = float(t.item())
+        assert bool(torch.isfinite(out_ref).all())
+        result["with_refinement_net"] = {"workload": "deq+lin+hal+ref (test_real_refinement.py:86-110), same batch",
+                                         "ms_per_step": round(rdt / args.steps * 1e3, 3),
+                                         "images_per_s": round(args.batch * n_gpus * args.steps / rdt, 3)}
+        del out_ref, run_ref, ref_net
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
     if rank == 0 and not args.no_roofline:

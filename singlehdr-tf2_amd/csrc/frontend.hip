@@ -81,7 +81,11 @@ __device__ __forceinline__ float frontend_channel(const float* __restrict__ img,
   else if (ch < 93) { idx = ch - 45; B = 16; }
   else return 0.0f;
   const int bin = idx / 3, c = idx - bin * 3;
-  return soft_bin(rgb[c], bin + 1, (float)(2 * B), (float)B, 1.0f / (float)B);
+  // B is 4, 8 or 16 here: 1/(2B) is a power of two, so (2i-1) * (1/(2B)) IS the correctly rounded quotient (2i-1)/(2B) -- the
+  // IEEE divide of soft_bin (needed for arbitrary B) is replaced by one exact multiply; d*B and 1/B are exact as well
+  const float centre = (float)(2 * bin + 1) * (0.5f / (float)B);
+  const float d = fabsf(__fsub_rn(rgb[c], centre));
+  return d < 1.0f / (float)B ? __fsub_rn(1.0f, __fmul_rn(d, (float)B)) : 0.0f;
 }
 
 // grid.y = image row (n*H + h), grid.x covers the W * QPP quads of that row: no runtime division
