@@ -78,7 +78,7 @@ def conv_flops(x, w, stride, cout_valid=None):
     return 2.0 * n * ho * wo * cin * cout * kh * kw
 
 
-def conv_variant(w, x, x2, algo):
+def conv_variant(w, x, x2, algo, stride=1):
     """Which kernel shdr_conv2d_fwd_f32 dispatches to (mirrors csrc/conv.hip)."""
     c1 = x.shape[3]
     c2 = 0 if x2 is None else x2.shape[3]
@@ -86,6 +86,9 @@ def conv_variant(w, x, x2, algo):
     mfma_ok = c1 % 4 == 0 and c2 % 4 == 0 and cout % 16 == 0
     if algo == 2 or (algo == 0 and not mfma_ok):
         return "conv_direct_kernel"
+    narrow = (c2 == 0 and c1 in (4, 8, 12, 16)) or (c1 == 16 and c2 == 16)                 # rega_ok() of conv.hip
+    if algo == 0 and stride == 1 and cout in (16, 32) and narrow and w.shape[0] * w.shape[1] * (c1 + c2) * cout * 4 <= 100 * 1024:
+        return "conv_rega_kernel<%d>" % cout
     bn = 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
     return "conv_mfma_dma_kernel<128,%d>" % bn
 
@@ -200,7 +203,7 @@ def main():
                 depth[0] -= 1
             e1.record()
             label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
-                     "winograd_fused_kernel" if wino == "fused" else conv_variant(w, x, x2, kw.get("algo", 0)))
+                     "winograd_fused_kernel" if wino == "fused" else conv_variant(w, x, x2, kw.get("algo", 0), stride))
             records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
                             "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
                                                         0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),

@@ -17,6 +17,7 @@
 //      cannot fill (Cin = 3/6/9, Cout = 3).
 //
 // Replaces the TF op call sites listed at shdr_conv2d_fwd_f32 in include/shdr.h.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "shdr_internal.h"
@@ -584,6 +585,114 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Register-A variant for the narrow full-resolution layers of the U-Nets (Dequantization- / Refinement-Net: 7x7 16->16,
+// 7x7 4->16, 5x5 16->32, 3x3 32->16, 3x3 16+16->16, ...).  With Cout = 16 / 32 every activation value feeds exactly one / two
+// MFMAs, and staging it through LDS-DMA runs into the LDS-DMA throughput of a CU (~30 GB/s, the same ceiling the filter
+// stream of the fused Winograd kernel hit): conv_mfma_dma_kernel<128,16> moves 137 B per kFLOP and sits at 41-51 TFLOP/s.
+// Here the A operand never touches LDS: lane (fi = pixel of a 16-pixel row segment, fg = channel group) loads its own
+// float4 = channels 4fg..4fg+3 of pixel fi + tap straight from global memory (one fully coalesced 1 KiB wave load per
+// (row segment, tap, 16-channel group)); its component s is the A value of k-step s.  The whole filter lives in LDS for
+// the lifetime of a PERSISTENT block (loaded once; image [tap][16-channel group][s][fg][cout] so the four lane groups of
+// a B read hit 64 consecutive floats).  Padding: rows outside the image skip the tap (wave-uniform), columns are zeroed
+// per lane.  Shares ConvArgs and the fused epilogue with the other MFMA kernels.
+//   CT = channels per tap: 4 (3-channel images zero-padded to 4), 16, or 32 (one source, or 16 + 16 concatenated sources).
+// ---------------------------------------------------------------------------
+template <int MT, int NT, int CT>
+__global__ __launch_bounds__(256) void conv_rega_kernel(const ConvArgs a) {
+  static_assert(CT == 4 || CT == 16 || CT == 32, "channels per tap");
+  constexpr int G = CT == 4 ? 1 : CT / 16;           // 16-channel groups per tap
+  constexpr int KS = CT == 4 ? 1 : 4;                // k-steps per group
+  constexpr int COUT = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // filter image [ntaps][G][KS][4][COUT]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fg = lane >> 4;
+
+  // ---- filter -> LDS, once per block ---------------------------------------------------------------------------------
+  {
+    const int total = a.ntaps * CT * COUT;
+    for (int e = tid; e < total; e += 256) {
+      const int co = e % COUT;
+      int r = e / COUT;
+      const int ch = r % CT, tap = r / CT;
+      const int g = CT == 4 ? 0 : ch >> 4, c16 = ch & 15;
+      const int s = CT == 4 ? 0 : c16 & 3, grp = CT == 4 ? ch : c16 >> 2;
+      float v = 0.0f;
+      if (co < a.Cout && ch < a.Ct)
+        v = a.w[((size_t)tap * a.Ct + ch) * a.Cout + co] * ((CT == 32 && a.C2 > 0 && ch >= a.C1) ? a.x2_scale : 1.0f);
+      smem[(((tap * G + g) * KS + s) * 4 + grp) * COUT + co] = v;
+    }
+  }
+  __syncthreads();
+
+  constexpr int TH = 4 * MT;                          // pixel tile: TH rows x 16 columns, wave w owns rows w*MT .. w*MT+MT-1
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int pm = tile;
+    const int tx = pm % a.tiles_x;
+    pm /= a.tiles_x;
+    const int ty = pm % a.tiles_y;
+    const int img = pm / a.tiles_y;
+    const int oh0 = ty * TH, ow0 = tx * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int iw0 = ow0 + fi - a.pad_l;               // input column of tap kw = 0
+    const size_t img_base = (size_t)img * a.H * a.W;
+    // (an explicit next-tap register prefetch measured 5-10 % slower than leaving the schedule to the compiler and the
+    //  8-12 resident waves per CU)
+    for (int kh = 0; kh < a.KH; ++kh) {
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int iw = iw0 + kw;
+        const bool col_ok = (unsigned)iw < (unsigned)a.W;
+        const int iwc = col_ok ? iw : 0;
+        const float* wl = smem + ((kh * a.KW + kw) * G) * KS * 4 * COUT + fg * COUT + fi;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          // this lane's channels of the tap: 4fg..4fg+3 of group g (CT = 4: channel fg)
+          const float* src = (CT == 32 && g == 1 && a.C2 > 0) ? a.x2 : a.x1;
+          const int cs = (CT == 32 && g == 1 && a.C2 > 0) ? a.C2 : a.C1;
+          const int coff = (CT == 32 && g == 1 && a.C2 == 0) ? 16 : 0;
+          float4 av[MT];
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            const int ih = oh0 + wave * MT + mi + kh - a.pad_t;        // wave-uniform
+            const bool ok = col_ok && (unsigned)ih < (unsigned)a.H && (CT != 16 || 4 * fg < cs);
+            const size_t pix = img_base + (size_t)(ok ? ih : 0) * a.W + iwc;
+            if (CT == 4) {
+              const float t = src[pix * cs + fg];
+              av[mi] = make_float4(ok ? t : 0.f, 0.f, 0.f, 0.f);
+            } else {
+              const float4 t = *reinterpret_cast<const float4*>(src + pix * cs + coff + (ok ? 4 * fg : 0));
+              av[mi] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            float bw[NT];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bw[ni] = wl[((g * KS + s) * 4) * COUT + ni * 16];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+              const float x = s == 0 ? av[mi].x : s == 1 ? av[mi].y : s == 2 ? av[mi].z : av[mi].w;
+#pragma unroll
+              for (int ni = 0; ni < NT; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[ni], x, acc[mi][ni], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    conv_epilogue<MT, NT>(a, acc, img, oh0, ow0, 0, wave, 0, fi, fg);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // VALU direct convolution: one thread = one output pixel x CPT couts.
 // Filter taps are indexed uniformly across the block -> scalar loads.
 // ---------------------------------------------------------------------------
@@ -700,6 +809,44 @@ int launch_mfma(ConvArgs& a, hipStream_t st) {
   return fast ? launch_mfma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_impl<BM, BN, WM, WN, false>(a, st);
 }
 
+template <int MT, int NT, int CT>
+int launch_rega(ConvArgs& a, hipStream_t st) {
+  constexpr int TH = 4 * MT;
+  a.tiles_x = (a.Wo + 15) / 16;
+  a.tiles_y = (a.Ho + TH - 1) / TH;
+  const long ntiles = (long)a.N * a.tiles_y * a.tiles_x;
+  const int lds = a.ntaps * CT * NT * 16 * 4;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_lds = lds;
+  }
+  const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);          // resident blocks per CU (LDS-limited)
+  long grid = 256L * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((conv_rega_kernel<MT, NT, CT>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  return shdr::check_launch("conv_rega_kernel");
+}
+
+// narrow stride-1 layers the register-A kernel takes: Cout <= 32, 4 / 16 / 32 channels per tap, filter <= 100 KB of LDS
+inline bool rega_ok(const ConvArgs& a) {
+  if (a.stride != 1 || a.w_bstride != 0 || a.Cout > 32 || a.Cout % 16 != 0) return false;
+  const bool ct4 = a.C2 == 0 && a.C1 == 4, ct16 = a.C2 == 0 && (a.C1 == 8 || a.C1 == 12 || a.C1 == 16);
+  const bool ct32 = (a.C2 == 0 && a.C1 == 32) || (a.C1 == 16 && a.C2 == 16);
+  if (!(ct4 || ct16 || ct32)) return false;
+  if (a.C2 == 0 && a.C1 == 32) return false;       // measured: one 32-channel source is faster on the LDS-DMA kernel
+  return (long)a.ntaps * a.Ct * a.Cout * 4 <= 100 * 1024;
+}
+
+template <int NT>
+int dispatch_rega(ConvArgs& a, hipStream_t st) {
+  if (a.Ct == 4) return launch_rega<4, NT, 4>(a, st);
+  if (a.Ct <= 16) return launch_rega<4, NT, 16>(a, st);      // 8 / 12 channels: the missing lane groups read zeros
+  return launch_rega<4, NT, 32>(a, st);
+}
+
 template <int CPT>
 int launch_direct(ConvArgs& a, hipStream_t st) {
   const long npix = (long)a.N * a.Ho * a.Wo;
@@ -785,6 +932,8 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
                  "conv2d: MFMA path needs C1%%4==0, C2%%4==0, Cout%%16==0, 16-byte aligned tensors");
     if (a.Cout % 128 == 0) return launch_mfma<128, 128, 2, 2>(a, st);
     if (a.Cout % 64 == 0) return launch_mfma<128, 64, 4, 1>(a, st);
+    if (a.prec == 0 && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && getenv("SHDR_NO_REGA") == nullptr)
+      return a.Cout == 32 ? dispatch_rega<2>(a, st) : dispatch_rega<1>(a, st);
     if (a.Cout % 32 == 0) return launch_mfma<128, 32, 4, 1>(a, st);
     return launch_mfma<128, 16, 4, 1>(a, st);
   }

@@ -320,3 +320,36 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
         assert torch.equal(K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU), y)
     with pytest.raises(ValueError, match="Cout"):
         K.winograd_filter_packed(dev(np.ascontiguousarray(wt[..., :48])))
+
+
+@pytest.mark.parametrize("shape", [  # n, h, w, c1, c2, cout, k, cout_valid
+    (2, 20, 23, 16, 0, 16, 7, None),     # Dequantization-Net conv2
+    (1, 33, 18, 4, 0, 16, 7, None),      # conv1 on the 3-channel image padded to 4
+    (2, 16, 16, 12, 0, 16, 7, None),     # Refinement-Net conv1 on [A, B, C] padded to 12
+    (1, 19, 21, 16, 0, 32, 5, None),     # d2.conv1
+    (1, 18, 17, 32, 0, 32, 5, None),     # d2.conv2 (100 KB of filter in LDS)
+    (2, 17, 31, 32, 0, 16, 3, None),     # u1.conv1
+    (2, 16, 20, 16, 16, 16, 3, None),    # u1.conv2: concatenated sources
+    (1, 24, 16, 16, 0, 16, 3, 3),        # output head: 3 of 16 padded couts stored
+    (1, 8, 8, 8, 0, 16, 3, None)])
+def test_conv2d_register_a_kernel_parity(shdr, shape):
+    """conv_rega_kernel (narrow U-Net layers: activations global -> VGPR, filter resident in LDS) vs the float64 oracle and,
+    bit for bit where the summation order coincides, vs the LDS-DMA kernel it replaces in AUTO mode"""
+    n, h, w, c1, c2, cout, k, cv = shape
+    rng = np.random.default_rng(sum(x or 0 for x in shape))
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, c1)))
+    x2 = f32(rng.normal(size=(n, h, w, c2))) if c2 else None
+    wt = f32(rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2)))
+    if cv:
+        wt[..., cv:] = 0
+    b = f32(rng.normal(size=cv or cout))
+    res = f32(rng.normal(size=(n, h, w, cv or cout)))
+    kw = dict(x2=None if x2 is None else dev(x2), x2_scale=0.5 if c2 else 1.0, act1=K.ACT_LRELU, residual=dev(res), act2=K.ACT_RELU,
+              cout_valid=cv)
+    y = K.conv2d(dev(x), dev(wt), dev(b), **kw)                                    # AUTO -> register-A kernel
+    ref = oracle_conv(x if x2 is None else np.concatenate([x, 0.5 * x2], -1), wt[..., :cv] if cv else wt, b, act1=2)
+    ref = np.maximum(ref + res, 0)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    old = K.conv2d(dev(x), dev(wt), dev(b), algo=K.ALGO_MFMA, **kw)               # forced: the LDS-DMA / register-staged kernel
+    assert rel_err(host(y), host(old)) <= 5e-6
