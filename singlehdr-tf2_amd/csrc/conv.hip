@@ -597,7 +597,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
 // per lane.  Shares ConvArgs and the fused epilogue with the other MFMA kernels.
 //   CT = channels per tap: 4 (3-channel images zero-padded to 4), 16, or 32 (one source, or 16 + 16 concatenated sources).
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int CT>
+// KK = 3 / 5 / 7 (square filter, compile-time): one activation STRIP per filter row -- the 16 pixels of the segment plus the
+// KK-1 halo pixels to their right -- is loaded once (2 wave loads instead of KK) and the operand of tap kw is the strip shifted
+// by kw lanes inside each 16-lane DPP row (v_mov_b32 dpp row_shl:kw, the lanes that run off the row take the halo register via
+// row_shr:16-kw).  KK = 0: any filter shape, one load per tap.
+template <int KK>
+__device__ __forceinline__ float strip_shift(float a, float b, std::integral_constant<int, KK>) {
+  if constexpr (KK == 0) {
+    return a;
+  } else {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x110 + (16 - KK), 0xF, 0xF, false);     // row_shr:16-kw
+    return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(a), 0x100 + KK, 0xF, 0xF, false));   // row_shl:kw
+  }
+}
+
+template <int MT, int NT, int CT, int KK>
 __global__ __launch_bounds__(256) void conv_rega_kernel(const ConvArgs a) {
   static_assert(CT == 4 || CT == 16 || CT == 32, "channels per tap");
   constexpr int G = CT == 4 ? 1 : CT / 16;           // 16-channel groups per tap
@@ -644,45 +658,99 @@ __global__ __launch_bounds__(256) void conv_rega_kernel(const ConvArgs a) {
 
     const int iw0 = ow0 + fi - a.pad_l;               // input column of tap kw = 0
     const size_t img_base = (size_t)img * a.H * a.W;
-    // (an explicit next-tap register prefetch measured 5-10 % slower than leaving the schedule to the compiler and the
-    //  8-12 resident waves per CU)
-    for (int kh = 0; kh < a.KH; ++kh) {
-      for (int kw = 0; kw < a.KW; ++kw) {
-        const int iw = iw0 + kw;
-        const bool col_ok = (unsigned)iw < (unsigned)a.W;
-        const int iwc = col_ok ? iw : 0;
-        const float* wl = smem + ((kh * a.KW + kw) * G) * KS * 4 * COUT + fg * COUT + fi;
+    if constexpr (KK != 0) {
+      for (int kh = 0; kh < KK; ++kh) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          // this lane's channels of the tap: 4fg..4fg+3 of group g (CT = 4: channel fg)
           const float* src = (CT == 32 && g == 1 && a.C2 > 0) ? a.x2 : a.x1;
           const int cs = (CT == 32 && g == 1 && a.C2 > 0) ? a.C2 : a.C1;
           const int coff = (CT == 32 && g == 1 && a.C2 == 0) ? 16 : 0;
-          float4 av[MT];
+          float4 sa[MT], sb[MT];                      // strip: pixels iw0 + fi and iw0 + 16 + fi (halo, lanes fi < KK-1)
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi) {
             const int ih = oh0 + wave * MT + mi + kh - a.pad_t;        // wave-uniform
-            const bool ok = col_ok && (unsigned)ih < (unsigned)a.H && (CT != 16 || 4 * fg < cs);
-            const size_t pix = img_base + (size_t)(ok ? ih : 0) * a.W + iwc;
+            const bool row_ok = (unsigned)ih < (unsigned)a.H && (CT != 16 || 4 * fg < cs);
+            const bool ok_a = row_ok && (unsigned)iw0 < (unsigned)a.W;
+            const bool ok_b = row_ok && fi < KK - 1 && (unsigned)(iw0 + 16) < (unsigned)a.W;
+            const size_t row = img_base + (size_t)(row_ok ? ih : 0) * a.W;
             if (CT == 4) {
-              const float t = src[pix * cs + fg];
-              av[mi] = make_float4(ok ? t : 0.f, 0.f, 0.f, 0.f);
+              const float ta = src[(row + (ok_a ? iw0 : 0)) * cs + fg], tb = src[(row + (ok_b ? iw0 + 16 : 0)) * cs + fg];
+              sa[mi] = make_float4(ok_a ? ta : 0.f, 0.f, 0.f, 0.f);
+              sb[mi] = make_float4(ok_b ? tb : 0.f, 0.f, 0.f, 0.f);
             } else {
-              const float4 t = *reinterpret_cast<const float4*>(src + pix * cs + coff + (ok ? 4 * fg : 0));
-              av[mi] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+              const float4 ta = *reinterpret_cast<const float4*>(src + (row + (ok_a ? iw0 : 0)) * cs + coff + (ok_a ? 4 * fg : 0));
+              const float4 tb = *reinterpret_cast<const float4*>(src + (row + (ok_b ? iw0 + 16 : 0)) * cs + coff + (ok_b ? 4 * fg : 0));
+              sa[mi] = ok_a ? ta : make_float4(0.f, 0.f, 0.f, 0.f);
+              sb[mi] = ok_b ? tb : make_float4(0.f, 0.f, 0.f, 0.f);
             }
           }
+          auto tap = [&](auto kwc) {
+            constexpr int KW_ = decltype(kwc)::value;
+            const float* wl = smem + (((kh * KK + KW_) * G + g) * KS * 4) * COUT + fg * COUT + fi;
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            float bw[NT];
+            for (int s = 0; s < KS; ++s) {
+              float bw[NT];
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bw[ni] = wl[((g * KS + s) * 4) * COUT + ni * 16];
+              for (int ni = 0; ni < NT; ++ni) bw[ni] = wl[(s * 4) * COUT + ni * 16];
 #pragma unroll
+              for (int mi = 0; mi < MT; ++mi) {
+                const float va = s == 0 ? sa[mi].x : s == 1 ? sa[mi].y : s == 2 ? sa[mi].z : sa[mi].w;
+                const float vb = s == 0 ? sb[mi].x : s == 1 ? sb[mi].y : s == 2 ? sb[mi].z : sb[mi].w;
+                const float x = strip_shift(va, vb, kwc);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[ni], x, acc[mi][ni], 0, 0, 0);
+              }
+            }
+          };
+          tap(std::integral_constant<int, 0>{});
+          tap(std::integral_constant<int, 1>{});
+          tap(std::integral_constant<int, 2>{});
+          if constexpr (KK >= 5) { tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); }
+          if constexpr (KK >= 7) { tap(std::integral_constant<int, 5>{}); tap(std::integral_constant<int, 6>{}); }
+        }
+      }
+    } else {
+      // (an explicit next-tap register prefetch measured 5-10 % slower than leaving the schedule to the compiler and the
+      //  8-12 resident waves per CU)
+      for (int kh = 0; kh < a.KH; ++kh) {
+        for (int kw = 0; kw < a.KW; ++kw) {
+          const int iw = iw0 + kw;
+          const bool col_ok = (unsigned)iw < (unsigned)a.W;
+          const int iwc = col_ok ? iw : 0;
+          const float* wl = smem + ((kh * a.KW + kw) * G) * KS * 4 * COUT + fg * COUT + fi;
+  #pragma unroll
+          for (int g = 0; g < G; ++g) {
+            // this lane's channels of the tap: 4fg..4fg+3 of group g (CT = 4: channel fg)
+            const float* src = (CT == 32 && g == 1 && a.C2 > 0) ? a.x2 : a.x1;
+            const int cs = (CT == 32 && g == 1 && a.C2 > 0) ? a.C2 : a.C1;
+            const int coff = (CT == 32 && g == 1 && a.C2 == 0) ? 16 : 0;
+            float4 av[MT];
+  #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
-              const float x = s == 0 ? av[mi].x : s == 1 ? av[mi].y : s == 2 ? av[mi].z : av[mi].w;
-#pragma unroll
-              for (int ni = 0; ni < NT; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[ni], x, acc[mi][ni], 0, 0, 0);
+              const int ih = oh0 + wave * MT + mi + kh - a.pad_t;        // wave-uniform
+              const bool ok = col_ok && (unsigned)ih < (unsigned)a.H && (CT != 16 || 4 * fg < cs);
+              const size_t pix = img_base + (size_t)(ok ? ih : 0) * a.W + iwc;
+              if (CT == 4) {
+                const float t = src[pix * cs + fg];
+                av[mi] = make_float4(ok ? t : 0.f, 0.f, 0.f, 0.f);
+              } else {
+                const float4 t = *reinterpret_cast<const float4*>(src + pix * cs + coff + (ok ? 4 * fg : 0));
+                av[mi] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+            }
+  #pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              float bw[NT];
+  #pragma unroll
+              for (int ni = 0; ni < NT; ++ni) bw[ni] = wl[((g * KS + s) * 4) * COUT + ni * 16];
+  #pragma unroll
+              for (int mi = 0; mi < MT; ++mi) {
+                const float x = s == 0 ? av[mi].x : s == 1 ? av[mi].y : s == 2 ? av[mi].z : av[mi].w;
+  #pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[ni], x, acc[mi][ni], 0, 0, 0);
+              }
             }
           }
         }
@@ -809,7 +877,7 @@ int launch_mfma(ConvArgs& a, hipStream_t st) {
   return fast ? launch_mfma_impl<BM, BN, WM, WN, true>(a, st) : launch_mfma_impl<BM, BN, WM, WN, false>(a, st);
 }
 
-template <int MT, int NT, int CT>
+template <int MT, int NT, int CT, int KK>
 int launch_rega(ConvArgs& a, hipStream_t st) {
   constexpr int TH = 4 * MT;
   a.tiles_x = (a.Wo + 15) / 16;
@@ -818,7 +886,7 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
   const int lds = a.ntaps * CT * NT * 16 * 4;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT, KK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_lds = lds;
@@ -826,7 +894,7 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);          // resident blocks per CU (LDS-limited)
   long grid = 256L * per_cu;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((conv_rega_kernel<MT, NT, CT>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_rega_kernel<MT, NT, CT, KK>), dim3((unsigned)grid), dim3(256), lds, st, a);
   return shdr::check_launch("conv_rega_kernel");
 }
 
@@ -840,11 +908,20 @@ inline bool rega_ok(const ConvArgs& a) {
   return (long)a.ntaps * a.Ct * a.Cout * 4 <= 100 * 1024;
 }
 
+template <int NT, int CT>
+int dispatch_rega_k(ConvArgs& a, hipStream_t st) {
+  const bool square = a.KH == a.KW && getenv("SHDR_REGA_NO_DPP") == nullptr;
+  if (square && a.KH == 3) return launch_rega<4, NT, CT, 3>(a, st);
+  if (square && a.KH == 5) return launch_rega<4, NT, CT, 5>(a, st);
+  if (square && a.KH == 7) return launch_rega<4, NT, CT, 7>(a, st);
+  return launch_rega<4, NT, CT, 0>(a, st);
+}
+
 template <int NT>
 int dispatch_rega(ConvArgs& a, hipStream_t st) {
-  if (a.Ct == 4) return launch_rega<4, NT, 4>(a, st);
-  if (a.Ct <= 16) return launch_rega<4, NT, 16>(a, st);      // 8 / 12 channels: the missing lane groups read zeros
-  return launch_rega<4, NT, 32>(a, st);
+  if (a.Ct == 4) return dispatch_rega_k<NT, 4>(a, st);
+  if (a.Ct <= 16) return dispatch_rega_k<NT, 16>(a, st);      // 8 / 12 channels: the missing lane groups read zeros
+  return dispatch_rega_k<NT, 32>(a, st);
 }
 
 template <int CPT>
