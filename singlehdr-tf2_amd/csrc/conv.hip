@@ -1,6 +1,9 @@
 // Convolution forward for the SingleHDR hot path on gfx950 (MI355X).
 //
-//  * conv_mfma_kernel   -- exact-fp32 implicit GEMM on v_mfma_f32_16x16x4_f32.
+//  * conv_mfma_dma_kernel -- exact-fp32 implicit GEMM on v_mfma_f32_16x16x4_f32, k-chunks staged HBM/L2 -> LDS by
+//      global_load_lds (the general kernel: any filter shape / stride, two concatenated sources, fused epilogue);
+//      PREC = 1 / 2 packs fp16 / bf16 operands for v_mfma_f32_16x16x32_* (BASELINE configs[4]).
+//  * conv_mfma_kernel     -- its register-staged twin (x2_scale != 1, SHDR_ALGO_MFMA_REG).
 //      GEMM view  D[cout][pixel] = sum_k W[k][cout] * X[pixel][k],
 //      k = (tap, cin) with cin contiguous (HWIO filters need no re-layout).
 //      A 2-D pixel tile (BM/16 rows x 16 columns) keeps the 3x3/5x5/7x7 halo of
@@ -9,12 +12,10 @@
 //      line per pixel.  Channel concat (two sources), the skip-scale of
 //      hallucination_net.skipLayer, bias, activation, folded inference BN,
 //      residual add and a second activation are fused.
-//      LDS: double-buffered, register-staged (global loads for chunk k+1 are
-//      issued before the MFMAs of chunk k, written after them).  Row strides
-//      (34 / BN+16 dwords) make every ds_read_b32 of an MFMA fragment
-//      conflict-free (bank = 2*i + g resp. 16*g + i).
-//  * conv_direct_kernel -- VALU direct convolution for the shapes the MFMA tile
-//      cannot fill (Cin = 3/6/9, Cout = 3).
+//  * conv_rega_kernel     -- narrow layers (Cout <= 32, <= 16 channels per source): activations global -> VGPR, DPP
+//      row shifts along the filter row, filter resident in LDS, persistent blocks.
+//  * conv_direct_kernel   -- VALU direct convolution for the shapes the MFMA tile cannot fill (Cin = 3/6/9, Cout = 3).
+//  (The 3x3 / stride-1 layers with Cin % 8 == 0 and Cout % 64 == 0 take winograd_fused.hip instead.)
 //
 // Replaces the TF op call sites listed at shdr_conv2d_fwd_f32 in include/shdr.h.
 #include <stdlib.h>
