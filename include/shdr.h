@@ -290,6 +290,13 @@ int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* 
                                    const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
                                    int act1, int act2, void* stream);
 
+/* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
+ * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then
+ * dw[3][3][Ct][Cout] (rows ci_off .. ci_off+Cx) += x_scale * G^T dU G.  x [N,H,W,Cx], dz [N,H,W,Cout];
+ * Cx % 32 == 0, Cout % 64 == 0.  Same call sites as shdr_conv2d_wgrad_f32. */
+int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, float* du, float* dw, int N, int H, int W, int Cx,
+                                   int Cout, int Ct, int ci_off, float x_scale, void* stream);
+
 /* ---- inference-tool image plumbing (test_real_refinement.py:119-155) -------------- */
 /* y[p][c] = x[p][reverse ? 2-c : c] / 255: the decoded 8-bit image as float in [0,1] (:125). */
 int shdr_u8_to_unit_f32(const uint8_t* x, float* y, int64_t npix, int reverse_channels, void* stream);

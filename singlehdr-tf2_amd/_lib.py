@@ -45,6 +45,7 @@ SIGNATURES = {
     "shdr_conv2d_winograd_fused_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
     "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),
     "shdr_crc32c": (ctypes.c_uint32, [c_ptr, ctypes.c_uint64, ctypes.c_uint32]),
     "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),

@@ -431,6 +431,16 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
     x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
     if x2 is not None:
         _chk(_d(x2), "x2")
+    if (WINOGRAD and PRECISION == "fp32" and (kh, kw) == (3, 3) and stride == 1 and c1 % 32 == 0 and c2 % 32 == 0
+            and cout % 64 == 0 and cin == c1 + c2 and cout == dz.shape[3] and tuple(dz.shape[:3]) == tuple(x.shape[:3])):
+        # Winograd-domain weight gradient (csrc/wgrad_winograd.hip): 2.25x fewer MFMAs than the direct form
+        n, h, w, _ = x.shape
+        dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+        for src, cx, off, sc in ((x, c1, 0, 1.0),) + (((_d(x2), c2, c1, float(x2_scale)),) if x2 is not None else ()):
+            du = torch.zeros((16, cx, cout), device=x.device, dtype=torch.float32)
+            _lib.check(lib.shdr_conv2d_wgrad_winograd_f32(_ptr(src), _ptr(dz), _ptr(du), _ptr(dw), n, h, w, cx, cout, cin, off, sc,
+                                                          _stream()), "shdr_conv2d_wgrad_winograd_f32")
+        return dw
     if cin != x.shape[3] + c2 or cout != dz.shape[3]:
         raise ValueError("conv2d_wgrad: filter %s does not match x %s (+%d) / dz %s"
                          % (tuple(w_shape), tuple(x.shape), c2, tuple(dz.shape)))

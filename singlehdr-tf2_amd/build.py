@@ -21,6 +21,7 @@ SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
     "wgrad.hip": [],
+    "wgrad_winograd.hip": [],
     "bwd.hip": [],
     "finetune.hip": [],
     "winograd.hip": [],

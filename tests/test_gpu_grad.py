@@ -42,6 +42,9 @@ CONV_GRAD_CASES = [
     ("c16_3_tanh_direct", 1, 12, 12, 16, 0, 3, 3, 1, 3, 1.0),
     ("c3p3_3_1x1_relu_direct", 1, 12, 12, 3, 3, 3, 1, 1, 1, 1.0 / 255),
     ("c96_64_big_slices", 2, 40, 40, 96, 0, 64, 3, 1, 1, 1.0),
+    ("wino_wgrad_ragged_64_64", 2, 13, 19, 64, 0, 64, 3, 1, 2, 1.0),          # Winograd-domain wgrad: odd H, W % 16 != 0
+    ("wino_wgrad_concat_64_64_to_128", 1, 18, 34, 64, 64, 128, 3, 1, 1, 0.5),   # two sources, x2 scale
+    ("wino_wgrad_256_64_many_units", 3, 32, 48, 256, 0, 64, 3, 1, 0, 1.0),
 ]
 
 
