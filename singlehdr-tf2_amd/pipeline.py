@@ -227,6 +227,80 @@ class JointTrainStep:
         return out
 
 
+class TrainStep:
+    """The per-network `*_train_step(ds)` closures of train.py:164-244 (`--deq` / `--lin` / `--hal`): one network, its own
+    loss, Adam 1e-4 on its own variables (train.py:19).  Same kernels and tape as the joint step; the differences are the
+    Linearization loss weights (L2 + 0.1 * crf here, 10 * L2 + crf in joint_training.py:160) and the learning rate.
+
+        step = TrainStep("deq", deq_net);            pred,               = step((ldr, jpeg_img_float, loss_mask))
+        step = TrainStep("lin", lin_net);            b_pred, crf_mean    = step((ldr, clipped_hdr_t, loss_mask, invcrf))
+        step = TrainStep("hal", hal_net, vgg, vgg2); pred, y_final, alpha = step((hdr_t, clipped_hdr_t, loss_mask))
+    """
+
+    LEARNING_RATE = 1e-4   # train.py:19
+    THRESHOLD = 0.12       # train.py:209
+
+    def __init__(self, which, net, vgg=None, vgg2=None, lr=None, process_group=None, world_size=1):
+        if which not in ("deq", "lin", "hal"):
+            raise ValueError("TrainStep: which must be 'deq', 'lin' or 'hal'")
+        if which == "hal" and vgg is None:
+            raise ValueError("TrainStep('hal'): the perceptual loss needs a Vgg16")
+        self.which, self.net, self._vgg, self._vgg2 = which, net, vgg, vgg2 or vgg
+        self.params = FlatParams([net])
+        self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
+        self.pg, self.world = process_group, world_size
+        self.last_loss = None
+
+    def forward(self, ds):
+        """(per-sample loss [b], the list the reference's step returns)"""
+        if self.which == "deq":                      # train.py:165-177
+            ldr, jpeg_img_float, loss_mask = ds
+            pred = K.clip(self.net(jpeg_img_float, training=True), 0.0, 1.0)
+            return K.diff_loss(pred, ldr, 0) * loss_mask.reshape(-1), [pred]
+        if self.which == "lin":                      # train.py:183-197
+            ldr, clipped_hdr_t, loss_mask, invcrf = ds
+            pred_invcrf = self.net(ldr, training=True)
+            pred_lin_ldr = tf_utils.apply_rf(ldr, pred_invcrf)
+            crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
+            loss = (K.diff_loss(pred_lin_ldr, clipped_hdr_t, 0) + 0.1 * crf_loss) * loss_mask.reshape(-1)
+            return loss, [pred_lin_ldr, crf_loss.detach().mean()]
+        hdr_t, clipped_hdr_t, loss_mask = ds         # train.py:203-244
+        mask = loss_mask.reshape(-1)
+        alpha = K.alpha_mask(clipped_hdr_t, self.THRESHOLD)
+        bgr_pred = self.net(clipped_hdr_t, training=True)
+        y_final = K.blend_const(clipped_hdr_t, alpha, bgr_pred, self.THRESHOLD)        # clipped + alpha * bgr2rgb(pred)
+        y_final_gamma = K.logc(y_final)
+        with torch.no_grad():
+            hdr_t_gamma = K.logc(hdr_t)
+            target_feats = self._vgg2(hdr_t_gamma)
+        feats = self._vgg(y_final_gamma)
+        perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
+        loss = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
+        tv_loss = K.tv_loss(y_final_gamma)
+        tv_w = mask
+        if self.pg is not None and self.world > 1:   # exact sharding of the batch-global TV mean, as in JointTrainStep
+            import torch.distributed as dist
+            msum = mask.sum()
+            dist.all_reduce(msum, group=self.pg)
+            tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
+        hal_loss = (loss + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
+        with torch.no_grad():
+            pred_rgb = tf_utils.bgr2rgb(bgr_pred.detach())
+        return hal_loss, [pred_rgb, y_final, alpha]
+
+    def __call__(self, ds, apply=True):
+        self.params.zero_grad()
+        loss, outputs = self.forward(ds)
+        loss.sum().backward()                        # tape.gradient of the per-sample loss = gradient of its sum
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        if apply:
+            self.optimizer.step()
+        self.last_loss = loss.detach()
+        return outputs
+
+
 class FinetuneStep:
     """The chained `train_step(ldr, hdr)` of finetune_real_dataset.py:144-183 (with the reference's
     `_hal(pred, ...)` typo read as `_hal(B_pred, ...)`): deq -> clip -> lin -> apply_rf

@@ -99,3 +99,60 @@ def test_training_reduces_the_loss(setup):
     for _ in range(4):
         last = float(step(setup["batch"], setup["inv"])["total"].sum())
     assert np.isfinite(last) and last < first, (first, last)
+
+
+def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
+    """train.py:164-244: `deq_train_step` and `hal_train_step` use exactly the joint step's loss terms, so their gradients
+    must equal the joint step's gradients of those networks; `lin_train_step` weighs its terms differently
+    (L2 + 0.1 * crf instead of 10 * L2 + crf) and is checked against the float64 reference."""
+    rng = np.random.default_rng(21)
+    P = {k: nets.init_params(getattr(nets, k + "_spec")(), 80 + i) for i, k in enumerate(("deq", "lin", "hal"))}
+    V = nets.init_params(nets.vgg_spec(), 83)
+    batch, inv = make_batch(rng, 2, 64)
+    ldr, jpeg, clipped, hdr_t, mask = (dev(t) for t in batch)
+    mods = dict(deq="dequantization_net", lin="linearization_net", hal="hallucination_net")
+
+    def fresh():
+        return {k: getattr(shdr, mods[k]).model().load_numpy(P[k]) for k in mods}
+    dd = {n: [V[n + ".kernel"], V[n + ".bias"]] for n in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3")}
+    vgg = shdr.vgg16.Vgg16(data_dict=dd)
+    a = fresh()
+    joint = shdr.pipeline.JointTrainStep(a["deq"], a["lin"], a["hal"], vgg, multi_stream=False)
+    jout = joint((ldr, jpeg, clipped, hdr_t, mask), dev(inv), apply=False)
+    jgrad = {k: torch.cat([t.grad.reshape(-1) for t in a[k].trainable_variables]).clone() for k in mods}
+
+    b = fresh()
+    s_deq = shdr.pipeline.TrainStep("deq", b["deq"])
+    (pred,) = s_deq((ldr, jpeg, mask), apply=False)
+    assert torch.equal(pred, jout["C_pred"]) and torch.equal(s_deq.last_loss, jout["loss_deq"].detach())
+    g = torch.cat([t.grad.reshape(-1) for t in b["deq"].trainable_variables])
+    assert float((g - jgrad["deq"]).abs().max()) <= 1e-6 * float(jgrad["deq"].abs().max())
+
+    s_hal = shdr.pipeline.TrainStep("hal", b["hal"], vgg)
+    pred_rgb, y_final, alpha = s_hal((hdr_t, clipped, mask), apply=False)
+    assert torch.equal(y_final, jout["A_pred"]) and torch.equal(alpha, jout["alpha"])
+    assert rel_err(host(s_hal.last_loss), host(jout["loss_hal"])) <= 1e-6
+    g = torch.cat([t.grad.reshape(-1) for t in b["hal"].trainable_variables])
+    assert float((g - jgrad["hal"]).norm() / jgrad["hal"].norm()) <= 1e-4       # same kernels, atomics reorder the sums
+    assert tuple(pred_rgb.shape) == tuple(y_final.shape)
+
+    s_lin = shdr.pipeline.TrainStep("lin", b["lin"])
+    b_pred, crf_mean = s_lin((ldr, clipped, mask, dev(inv)), apply=False)
+    assert torch.equal(b_pred, jout["B_pred"])
+    tP = R.params_to_torch(P["lin"])
+    t_inv = R.lin_forward(tP, R.T(batch[0]), emor_table, True)
+    t_b = R.apply_rf(R.T(batch[0]), t_inv)
+    crf = ((t_inv - R.T(inv)) ** 2).mean(dim=1)
+    l2 = ((t_b - R.T(batch[2])) ** 2).mean(dim=(1, 2, 3))
+    want = (l2 + 0.1 * crf) * R.T(batch[4]).reshape(-1)
+    assert rel_err(host(s_lin.last_loss), want.detach().numpy()) <= 1e-4
+    assert abs(float(crf_mean) - float(crf.mean())) <= 1e-4 * float(crf.mean())
+    want.sum().backward()
+    got = torch.cat([t.grad.reshape(-1) for t in b["lin"].trainable_variables]).double().cpu()
+    ref = torch.cat([tP[n].grad.reshape(-1) for n, _, tr in b["lin"].named_weights() if tr])
+    assert float((got - ref).norm() / ref.norm()) <= 5e-2                      # whole-net bar (test_gpu_grad.NET_L2_TOL)
+    # and the steps train: Adam 1e-4 on the step's own variables only
+    before = b["deq"].trainable_variables[0].detach().clone()
+    s_deq((ldr, jpeg, mask))
+    assert not torch.equal(b["deq"].trainable_variables[0].detach(), before)
+    assert s_deq.optimizer.lr == 1e-4 and s_deq.params.num_params == 1999779
