@@ -155,3 +155,25 @@ def test_corrupt_tensor_and_wrong_root(tmp_path):
         C.restore(pkg.dequantization_net.model(device=torch.device("cpu")), prefix, verify=False)
     with pytest.raises(KeyError, match="absent"):
         C.restore(pkg.hallucination_net.model(device=torch.device("cpu")), prefix, verify=False)
+
+
+def test_checkpoint_initialization_mirrors_the_reference_helper(tmp_path):
+    """tf_utils.checkpoint_initialization (tf_utils.py:149-169) + the save loop of joint_training.py:257-263"""
+    tu = pkg.tf_utils
+    torch.manual_seed(5)
+    m = pkg.refinement_net.model(device=torch.device("cpu"))
+    d = str(tmp_path / "checkpoints" / "ref")
+    ckpt, mgr = tu.checkpoint_initialization("ref", d, m, None)
+    assert os.path.isdir(d) and mgr.latest_checkpoint is None and int(ckpt.epoch) == 0
+    for _ in range(3):
+        ckpt.epoch.assign_add(1)
+    path = mgr.save()
+    assert path.endswith("ckpt-1") and mgr.latest_checkpoint == path
+    ckpt.epoch.assign_add(1)
+    assert mgr.save().endswith("ckpt-2")
+    torch.manual_seed(6)
+    m2 = pkg.refinement_net.model(device=torch.device("cpu"))
+    ckpt2, mgr2 = tu.checkpoint_initialization("ref", d, m2, None)          # restores ckpt-2
+    assert int(ckpt2.epoch) == 4 and mgr2.save().endswith("ckpt-3")
+    for (n, a, _), (_, b, _) in zip(m.named_weights(), m2.named_weights()):
+        assert torch.equal(a, b), n
