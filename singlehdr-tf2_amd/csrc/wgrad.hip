@@ -15,6 +15,7 @@
 //
 // Replaces GradientTape.gradient through tf.keras.layers.Conv2D (joint_training.py:185,
 // train.py:175,195,242, finetune_real_dataset.py:177).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "shdr_internal.h"
@@ -221,6 +222,168 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
+// All-taps weight gradient for the narrow full-resolution layers (Cin = 16 / 32 per source, Cout = 16 / 32, stride 1, square
+// 3x3 / 5x5 / 7x7 filters: the U-Nets of the Dequantization- and Refinement-Net).  wgrad_mfma_kernel<16,16> gives every filter
+// tap its own block, so the 32-pixel X and dZ tiles (4 KB) are DMA-staged again for each of the up to 49 taps and feed 8
+// MFMAs: 250 B of LDS-DMA per kFLOP, which is the LDS-DMA ceiling of a CU (33 TFLOP/s).  Here ONE block covers all taps of a
+// 32-pixel row segment: the KK x (32 + KK - 1) input patch and the 32 gradient pixels are staged once per chunk (24 B per
+// kFLOP at 7x7) and the four waves split the taps -- wave w keeps the tiles of taps w, w+4, ... (<= 13) in registers, reads
+// the dZ operand once per k-step and the X operand of a tap at its shifted pixel offset (consecutive lanes = consecutive
+// channels and pixels: conflict-free b32 reads).  Partial tiles go to dW by fp32 atomics once per block.
+template <int KK, int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_alltaps_kernel(const WgradArgs a) {
+  constexpr int NTAPS = KK * KK, TPW = (NTAPS + 3) / 4;
+  constexpr int CX = 16 * MT, CO = 16 * NT;
+  constexpr int PWD = 32 + KK - 1;                       // patch width in pixels
+  constexpr int XQ = CX / 4, ZQ = CO / 4;                // 16-byte quads per pixel
+  constexpr int X_SLOTS = KK * PWD * XQ, Z_SLOTS = 32 * ZQ;
+  constexpr int X_INSTR = (X_SLOTS + 63) / 64, Z_INSTR = (Z_SLOTS + 63) / 64;
+  constexpr int XJ = (X_INSTR + 3) / 4, ZJ = (Z_INSTR + 3) / 4;
+  constexpr int X_FLOATS = X_INSTR * 256, Z_FLOATS = Z_INSTR * 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (X_FLOATS + Z_FLOATS)];
+  float* Xs = smem;
+  float* Zs = smem + 2 * X_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, fi = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* zero = g_wg_zero_page;
+
+  f32x4 acc[TPW][MT][NT];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[j][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int segs = (a.Wo + 31) >> 5;
+  const int units = a.N * a.Ho * segs;
+  const int u_begin = blockIdx.x * a.slice, u_end = min(u_begin + a.slice, units);
+
+  auto dma_unit = [&](int u, int buf) {
+    const int seg = u % segs;
+    const int q = u / segs;
+    const int oh = q % a.Ho, n = q / a.Ho;
+    const int ow0 = seg * 32;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      if (wave + 4 * j < X_INSTR) {
+        const int slot = (wave + 4 * j) * 64 + lane;
+        const int pix = slot / XQ, pq = slot - pix * XQ;
+        const int row = pix / PWD, col = pix - row * PWD;
+        const int ih = oh + row - a.pad_t, iw = ow0 + col - a.pad_l;
+        const bool ok = slot < X_SLOTS && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        const float* p = ok ? a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.Cx + 4 * pq : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Xs + buf * X_FLOATS + (wave + 4 * j) * 256), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < ZJ; ++j) {
+      if (wave + 4 * j < Z_INSTR) {
+        const int slot = (wave + 4 * j) * 64 + lane;
+        const int pix = slot / ZQ, pq = slot - pix * ZQ;
+        const int ow = ow0 + pix;
+        const bool ok = slot < Z_SLOTS && ow < a.Wo;
+        const float* p = ok ? a.dz + ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Cout + 4 * pq : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Zs + buf * Z_FLOATS + (wave + 4 * j) * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  if (u_begin < u_end) dma_unit(u_begin, 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int u = u_begin; u < u_end; ++u) {
+    const int b = (u - u_begin) & 1;
+    const float* xb = Xs + b * X_FLOATS + fi;
+    const float* zb = Zs + b * Z_FLOATS + fi;
+    // dZ operand of the 8 k-steps (pixel 4s + fg), shared by all taps of this wave
+    float bz[8][NT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bz[s][ni] = zb[(4 * s + fg) * CO + ni * 16];
+    // X operands: every LDS read of the chunk is issued before the next chunk's DMA (see winograd_fused.hip); the taps are
+    // processed in two halves to bound the live registers
+    constexpr int H0 = (TPW + 1) / 2;
+    float xa[H0][8][MT];
+    auto load_taps = [&](int j0, int cnt) {
+#pragma unroll
+      for (int jj = 0; jj < H0; ++jj) {
+        const int j = j0 + jj;
+        const int t = wave + 4 * j;
+        if (jj < cnt && t < NTAPS) {                     // wave-uniform
+          const int kh = t / KK, kw = t - kh * KK;
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) xa[jj][s][mi] = xb[((kh * PWD) + 4 * s + fg + kw) * CX + mi * 16];
+        }
+      }
+    };
+    auto mfma_taps = [&](int j0, int cnt) {
+#pragma unroll
+      for (int jj = 0; jj < H0; ++jj) {
+        const int j = j0 + jj;
+        if (jj < cnt && wave + 4 * j < NTAPS) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NT; ++ni)
+                acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj][s][mi], bz[s][ni], acc[j][mi][ni], 0, 0, 0);
+        }
+      }
+    };
+    load_taps(0, H0);
+    mfma_taps(0, H0);
+    load_taps(H0, TPW - H0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 < u_end) dma_unit(u + 1, b ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_taps(H0, TPW - H0);
+    __syncthreads();
+  }
+  // D[row = ci][col = co]: lane holds rows 4*fg + r, column fi
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave + 4 * j;
+    if (t < NTAPS) {
+      float* dwt = a.dw + (size_t)t * a.Ct * a.Cout;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            atomicAdd(dwt + (size_t)(a.ci_off + mi * 16 + 4 * fg + r) * a.Cout + ni * 16 + fi, acc[j][mi][ni][r] * a.x_scale);
+    }
+  }
+}
+
+template <int KK, int MT, int NT>
+int launch_wgrad_alltaps(WgradArgs& a, hipStream_t st) {
+  const long units = (long)a.N * a.Ho * ((a.Wo + 31) / 32);
+  long blocks = 1024;                                     // 4 per CU; bounds the atomics (taps x 256 x MT x NT per block)
+  if (blocks > units) blocks = units;
+  a.slice = (int)((units + blocks - 1) / blocks);
+  blocks = (units + a.slice - 1) / a.slice;
+  hipLaunchKernelGGL((wgrad_alltaps_kernel<KK, MT, NT>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return shdr::check_launch("wgrad_alltaps_kernel");
+}
+
+template <int MT, int NT>
+int dispatch_alltaps(WgradArgs& a, hipStream_t st) {
+  if (a.KH == 3) return launch_wgrad_alltaps<3, MT, NT>(a, st);
+  if constexpr (MT * NT <= 2) {
+    if (a.KH == 5) return launch_wgrad_alltaps<5, MT, NT>(a, st);
+  }
+  if constexpr (MT * NT == 1) {
+    if (a.KH == 7) return launch_wgrad_alltaps<7, MT, NT>(a, st);
+  }
+  return shdr::fail(SHDR_E_SHAPE, "wgrad_alltaps: no variant for %dx%d, %d -> %d", a.KH, a.KW, a.Cx, a.Cout);
+}
+
 // VALU fallback: one block per (pixel slice); threads stride over (tap, ci, co).
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(const WgradArgs a) {
   const int p_begin = blockIdx.x * a.slice;
@@ -355,6 +518,16 @@ extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, 
   const bool mfma_ok = (a.Cx % 16 == 0) && (a.Cout % 16 == 0) && shdr::aligned16(x) && shdr::aligned16(dz);
   a.prec = (d->algo == SHDR_ALGO_MFMA_F16 || d->algo == SHDR_ALGO_AUTO_F16) ? 1
            : (d->algo == SHDR_ALGO_MFMA_BF16 || d->algo == SHDR_ALGO_AUTO_BF16) ? 2 : 0;
+  // (also in the reduced-precision modes: the exact-fp32 all-taps kernel is 2x faster than the fp16-operand narrow kernel,
+  //  which sits at the same LDS-DMA ceiling, and errs on the accurate side)
+  const bool auto_algo = d->algo == SHDR_ALGO_AUTO || d->algo == SHDR_ALGO_AUTO_F16 || d->algo == SHDR_ALGO_AUTO_BF16;
+  if (mfma_ok && auto_algo && a.stride == 1 && (a.Cx == 16 || a.Cx == 32) &&
+      (a.Cout == 16 || a.Cout == 32) && a.KH == a.KW && (a.KH == 3 || a.KH == 5 || a.KH == 7) && a.Ho == a.H && a.Wo == a.W &&
+      (a.KH == 3 || (a.KH == 5 && a.Cx * a.Cout <= 512) || (a.KH == 7 && a.Cx == 16 && a.Cout == 16)) &&   // <= 256 VGPRs
+      getenv("SHDR_NO_ALLTAPS") == nullptr) {
+    if (a.Cx == 16) return a.Cout == 16 ? dispatch_alltaps<1, 1>(a, st) : dispatch_alltaps<1, 2>(a, st);
+    return a.Cout == 16 ? dispatch_alltaps<2, 1>(a, st) : dispatch_alltaps<2, 2>(a, st);
+  }
   if (mfma_ok && d->algo != SHDR_ALGO_DIRECT) {
     if (a.Cx % 128 == 0) return dispatch_n<128>(a, st);
     if (a.Cx % 64 == 0) return dispatch_n<64>(a, st);

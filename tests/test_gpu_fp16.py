@@ -102,9 +102,11 @@ def test_conv_backward_reduced_precision(shdr, prec):
                     gy = torch.randn(y.shape, generator=g).cuda()
                 (y * gy).sum().backward()
             grads[p] = [t.grad.clone() for t in xs + [wt]]
-        for a, b in zip(grads[prec], grads["fp32"]):
-            err = maxrel(a, b)
-            assert 0.0 < err <= 2 * TOL[prec], (err, tuple(a.shape))
+        errs = [maxrel(a, b) for a, b in zip(grads[prec], grads["fp32"])]
+        assert all(e <= 2 * TOL[prec] for e in errs), errs
+        # dgrad always runs on reduced-precision operands; the weight gradient of the narrow layers (16 / 32 channels) takes
+        # the exact-fp32 all-taps kernel in every mode (faster than the fp16-operand narrow kernel), so its error may be 0
+        assert errs[0] > 0.0, errs
 
 
 @pytest.fixture(scope="module")

@@ -124,7 +124,8 @@ def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     b = fresh()
     s_deq = shdr.pipeline.TrainStep("deq", b["deq"])
     (pred,) = s_deq((ldr, jpeg, mask), apply=False)
-    assert torch.equal(pred, jout["C_pred"]) and torch.equal(s_deq.last_loss, jout["loss_deq"].detach())
+    assert torch.equal(pred, jout["C_pred"])
+    assert rel_err(host(s_deq.last_loss), host(jout["loss_deq"])) <= 1e-6        # the loss reduction sums with atomics
     g = torch.cat([t.grad.reshape(-1) for t in b["deq"].trainable_variables])
     assert float((g - jgrad["deq"]).abs().max()) <= 1e-6 * float(jgrad["deq"].abs().max())
 
