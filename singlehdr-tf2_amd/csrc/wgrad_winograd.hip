@@ -3,8 +3,10 @@
 // gradient), dU[xi][ci][co] = sum over tiles of V[xi][tile][ci] * Q[xi][tile][co] and dW = G^T dU G -- 16 MACs per tile and
 // (ci, co) instead of the 36 of the direct form (2.25x fewer MFMAs than wgrad_mfma_kernel).
 //
-//   block  = 32 input channels x 64 output channels x all 16 transform positions; 512 threads = 8 wavefronts, wave w owns
-//            xi = {2w, 2w+1}: 2 x (2 x 4 tiles of 16 x 16) fp32 accumulators = 64 registers; one block per CU.
+//   block  = 32 input channels x 64 output channels x all 16 transform positions; 256 threads = 4 wavefronts, wave w owns
+//            the row combination i = w with all four column combinations (xi = 4w .. 4w+3): 4 x (2 x 4 tiles of 16 x 16) fp32
+//            accumulators = 128 registers; TWO independent blocks per CU, so one block's read / transform phase overlaps
+//            the other's MFMAs (the 8-wave, one-block-per-CU mapping ran in lockstep: 135-147 TFLOP/s).
 //   K loop = Winograd tiles, 8 per chunk (one row segment of 2 x 16 output pixels): the 4 x 18 input patch (32 ci) and the
 //            2 x 16 gradient patch (64 co) go HBM/L2 -> LDS by global_load_lds, double buffered; every lane builds its MFMA
 //            operands from them on the fly -- A: V[xi][tile = 4s + lane>>4][ci = lane & 15] from 2 patch rows x 3 patch
@@ -45,7 +47,7 @@ struct WW {
 };
 
 template <int MTC>
-__global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_winograd_kernel(const WinoWgradArgs a) {
   constexpr int XQ = WW<MTC>::XQ, X_INSTR = WW<MTC>::X_INSTR, X_FLOATS = WW<MTC>::X_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                          // [2][72 pixels][XQ quads][4]
@@ -62,36 +64,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
 
   // ---- DMA: instruction j of this wave covers slots (wave + 8*j)*64 + lane; the geometry is recomputed per call (a few
   //      integer ops) instead of being kept in registers across the MFMA loop (it spilled to scratch) -----------------------
-  constexpr int XJ = (X_INSTR + 7) / 8;      // 3 per wave (the last one only on waves 0, 1)
+  constexpr int XJ = (X_INSTR + 3) / 4, ZJ = (Z_INSTR + 3) / 4;      // per wave (4 waves)
   auto dma_unit = [&](int u, int buf) {
     const int seg = u % a.segs;
     const int q = u / a.segs;
     const int ty = q % a.tiles_y, n = q / a.tiles_y;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      if ((wave + 8 * j) < X_INSTR) {
-        const int slot = (wave + 8 * j) * 64 + lane;
+      if ((wave + 4 * j) < X_INSTR) {
+        const int slot = (wave + 4 * j) * 64 + lane;
         const int pix = slot / XQ, pq = slot % XQ;
         const int row = (pix * 3641) >> 16;              // pix / 18 for pix < 72
         const int col = pix - row * 18;
         const int ih = 2 * ty - 1 + row, iw = 16 * seg - 1 + col;
         const bool ok = pix < XP_PIX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
         const float* p = ok ? a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.Cx + ci0 + 4 * (pq ^ ((4 * ((col >> 1) & 3)) & (XQ - 1))) : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Xs + buf * X_FLOATS + (wave + 8 * j) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Xs + buf * X_FLOATS + (wave + 4 * j) * 256), 16, 0, 0);
       }
     }
-    {
-      const int slot = wave * 64 + lane;     // Z_INSTR == 8: one instruction per wave
+#pragma unroll
+    for (int j = 0; j < ZJ; ++j) {
+      const int slot = (wave + 4 * j) * 64 + lane;       // Z_INSTR == 8: two instructions per wave
       const int pix = slot >> 4, pq = slot & 15;
       const int oh = 2 * ty + (pix >> 4), ow = 16 * seg + (pix & 15);
       const bool ok = oh < a.H && ow < a.W;
       const float* p = ok ? a.dz + ((size_t)(n * a.H + oh) * a.W + ow) * a.Cout + co0 + 4 * (pq ^ (4 * (((pix & 15) >> 1) & 3))) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Zs + buf * Z_FLOATS + wave * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Zs + buf * Z_FLOATS + (wave + 4 * j) * 256), 16, 0, 0);
     }
   };
 
-  // ---- operand geometry ------------------------------------------------------------------------------------------------
-  const int wi = wave >> 1, jp = wave & 1;
+  // ---- operand geometry: wave w owns the row combination i = w and all four column combinations j (xi = 4w .. 4w+3) ------
+  const int wi = wave;
   // V row i = d[ra] + sr * d[rb] (B^T): i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
   const int ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
   const int rb = wi == 3 ? 3 : (wi == 2 ? 1 : 2);
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
   const float za = wi == 3 ? 0.0f : 1.0f;
   const float zb = wi == 0 ? 0.0f : (wi == 1 ? 1.0f : -1.0f);
 
-  f32x4 acc[2][MTC][4];
+  f32x4 acc[4][MTC][4];
 #pragma unroll
-  for (int x2 = 0; x2 < 2; ++x2)
+  for (int x2 = 0; x2 < 4; ++x2)
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
     const float* xb = Xs + b * X_FLOATS;
     const float* zs = Zs + b * Z_FLOATS;
     // ---- operands of both k-steps, built straight from LDS (all LDS reads of the chunk precede the next DMA issue) ----
-    float va[2][2][MTC], qb[2][2][4];        // [s][x2][mt] / [s][x2][nt]
+    float va[2][4][MTC], qb[2][4][4];        // [s][j][mt] / [s][j][nt]
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int tx = 4 * s + fg;             // tile column of this lane in k-step s
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) zv[nt][r][c] = zs[((r * 16 + col) * 16 + ((nt * 4 + (fi >> 2)) ^ swz)) * 4 + (fi & 3)];
         }
-      float xv[MTC][2][3];                   // [mt][row a / b][patch column jp + k]
+      float xv[MTC][2][4];                   // [mt][row a / b][patch column]
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int pc = 2 * tx + jp + k;      // patch column
+      for (int k = 0; k < 4; ++k) {
+        const int pc = 2 * tx + k;           // patch column
         const int swz = (4 * ((pc >> 1) & 3)) & (XQ - 1);
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) {
@@ -148,16 +151,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
       for (int nt = 0; nt < 4; ++nt) {
         const float r0 = za * zv[nt][0][0] + zb * zv[nt][1][0];
         const float r1 = za * zv[nt][0][1] + zb * zv[nt][1][1];
-        if (jp == 0) { qb[s][0][nt] = r0;      qb[s][1][nt] = r0 + r1; }       // j = 0: dY col 0; j = 1: col0 + col1
-        else         { qb[s][0][nt] = r0 - r1; qb[s][1][nt] = -r1; }           // j = 2: col0 - col1; j = 3: -col1
+        qb[s][0][nt] = r0;                   // j = 0: dY col 0
+        qb[s][1][nt] = r0 + r1;              // j = 1: col0 + col1
+        qb[s][2][nt] = r0 - r1;              // j = 2: col0 - col1
+        qb[s][3][nt] = -r1;                  // j = 3: -col1
       }
 #pragma unroll
       for (int mt = 0; mt < MTC; ++mt) {
-        float r[3];
+        float r[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) r[k] = xv[mt][0][k] + sr * xv[mt][1][k];
-        if (jp == 0) { va[s][0][mt] = r[0] - r[2]; va[s][1][mt] = r[1] + r[2]; }     // j = 0, 1 on patch columns 0, 1, 2
-        else         { va[s][0][mt] = r[1] - r[0]; va[s][1][mt] = r[0] - r[2]; }     // j = 2, 3 on patch columns 1, 2, 3
+        for (int k = 0; k < 4; ++k) r[k] = xv[mt][0][k] + sr * xv[mt][1][k];
+        va[s][0][mt] = r[0] - r[2];          // j = 0: c0 - c2
+        va[s][1][mt] = r[1] + r[2];          // j = 1: c1 + c2
+        va[s][2][mt] = r[2] - r[1];          // j = 2: c2 - c1
+        va[s][3][mt] = r[1] - r[3];          // j = 3: c1 - c3
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int x2 = 0; x2 < 2; ++x2)
+      for (int x2 = 0; x2 < 4; ++x2)
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_winograd_kernel(const WinoWgradA
 
   // ---- partial dU tiles: D[row = ci (4*fg + r)][col = co (fi)] --------------------------------------------------------------
 #pragma unroll
-  for (int x2 = 0; x2 < 2; ++x2) {
-    float* dst = a.du + (size_t)(2 * wave + x2) * a.Cx * a.Cout;
+  for (int x2 = 0; x2 < 4; ++x2) {
+    float* dst = a.du + (size_t)(4 * wave + x2) * a.Cx * a.Cout;
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
@@ -258,7 +265,7 @@ extern "C" int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, f
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_winograd_kernel<2>, dim3((unsigned)tiles, (unsigned)nslices), dim3(512), WW<2>::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(wgrad_winograd_kernel<2>, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), WW<2>::LDS_BYTES, st, a);
   if (int rc = shdr::check_launch("wgrad_winograd_kernel")) return rc;
   hipLaunchKernelGGL(winograd_dw_kernel, dim3(shdr::stream_grid((long)Cx * Cout)), dim3(256), 0, st, du, dw, Cx, Cout, Ct, ci_off,
                      x_scale);
