@@ -10,6 +10,8 @@
 // the reference does -- centre = fp32(2i-1)/fp32(2B) (IEEE divide),
 // d = |x - centre|, h = d < fp32(1/B) ? 1 - d*B : 0 with the multiply and the
 // subtract rounded separately (__fmul_rn/__fsub_rn forbid FMA contraction).
+#include <stdlib.h>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -115,6 +117,63 @@ __global__ __launch_bounds__(256) void lin_frontend_kernel(const float* __restri
   }
 }
 
+// Row-segment version of the fused front end: a block owns 64 consecutive pixels of one image row and builds their 96-channel
+// feature rows in LDS -- wave 0 the 9 image / sobel channels (one pixel per lane), all four waves the 84 histogram channels
+// (thread = (pixel, channel) pairs; bin centre, bin count and colour index come from the channel number by arithmetic, no
+// divergent paths) -- then streams the 24 KB tile to HBM with fully coalesced float4 stores.  The per-quad kernel above mixes
+// the sobel and histogram code paths in every wave and reaches 1.9 TB/s of stores; this one is store-bound.
+template <int YC>
+__global__ __launch_bounds__(256) void lin_frontend_rows_kernel(const float* __restrict__ img, float* __restrict__ y, int N, int H,
+                                                                int W) {
+  constexpr int PX = 64;
+  __shared__ __attribute__((aligned(16))) float tile[PX * 96];
+  __shared__ float rgbs[PX * 3];
+  const int row = blockIdx.y;
+  const int h = row % H;
+  const long ibase = (long)(row / H) * H * W;
+  const int w0 = blockIdx.x * PX;
+  const int tid = threadIdx.x;
+  if (tid < PX) {                                    // wave 0: image + sobel (linearization_net.py:312-314)
+    const int w = min(w0 + tid, W - 1);
+    const long p = ibase + (long)h * W + w;
+    const int hm = reflect(h - 1, H), hp = reflect(h + 1, H), wm = reflect(w - 1, W), wp = reflect(w + 1, W);
+    float* t = tile + tid * 96;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      auto at = [&](int hh, int ww) { return img[(ibase + (long)hh * W + ww) * 3 + c]; };
+      const float v = img[p * 3 + c];
+      t[c] = v;
+      rgbs[tid * 3 + c] = v;
+      t[3 + 2 * c] = (at(hp, wm) - at(hm, wm)) + 2.0f * (at(hp, w) - at(hm, w)) + (at(hp, wp) - at(hm, wp));
+      t[4 + 2 * c] = (at(hm, wp) - at(hm, wm)) + 2.0f * (at(h, wp) - at(h, wm)) + (at(hp, wp) - at(hp, wm));
+    }
+    t[93] = 0.0f; t[94] = 0.0f; t[95] = 0.0f;
+  }
+  __syncthreads();
+  // histogram channels 9 .. 92: 84 per pixel, 5376 per block, 21 per thread; consecutive threads = consecutive channels
+  for (int e = tid; e < PX * 84; e += 256) {
+    const int px = e / 84, k = e - px * 84;           // k: 0..11 -> B = 4, 12..35 -> B = 8, 36..83 -> B = 16
+    const int lvl = k < 12 ? 0 : (k < 36 ? 1 : 2);
+    const int idx = k - (lvl == 0 ? 0 : (lvl == 1 ? 12 : 36));
+    const int B = 4 << lvl;
+    const int bin = idx / 3, c = idx - bin * 3;
+    // 1/(2B) is a power of two: (2i-1) * (1/(2B)) is the correctly rounded quotient of soft_bin's IEEE divide
+    const float centre = (float)(2 * bin + 1) * (0.5f / (float)B);
+    const float d = fabsf(__fsub_rn(rgbs[px * 3 + c], centre));
+    tile[px * 96 + 9 + k] = d < 1.0f / (float)B ? __fsub_rn(1.0f, __fmul_rn(d, (float)B)) : 0.0f;
+  }
+  __syncthreads();
+  const int npx = min(PX, W - w0);
+  float* yo = y + (ibase + (long)h * W + w0) * YC;
+  if (YC == 96) {
+    const int nq = npx * 24;
+    for (int q = tid; q < nq; q += 256) *reinterpret_cast<float4*>(yo + 4 * q) = *reinterpret_cast<const float4*>(tile + 4 * q);
+  } else {
+    const int n = npx * 93;
+    for (int e = tid; e < n; e += 256) yo[e] = tile[(e / 93) * 96 + e % 93];
+  }
+}
+
 }  // namespace
 
 extern "C" int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, int C, int B,
@@ -145,8 +204,14 @@ extern "C" int shdr_lin_frontend_fwd_f32(const float* img, float* y, int N, int 
   SHDR_REQUIRE(y_channels == 93 || y_channels == 96, SHDR_E_SHAPE, "lin_frontend: y_channels must be 93 or 96");
   SHDR_REQUIRE((long)N * H <= 65535, SHDR_E_SHAPE, "lin_frontend: N*H must be <= 65535");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)((W * 24 + 255) / 256), (unsigned)(N * H));
-  if (y_channels == 96) hipLaunchKernelGGL(lin_frontend_kernel<96>, grid, dim3(256), 0, st, img, y, N, H, W);
-  else hipLaunchKernelGGL(lin_frontend_kernel<93>, grid, dim3(256), 0, st, img, y, N, H, W);
+  if (getenv("SHDR_FRONTEND_QUADS") != nullptr) {          // the per-quad kernel (kept for comparison)
+    const dim3 grid((unsigned)((W * 24 + 255) / 256), (unsigned)(N * H));
+    if (y_channels == 96) hipLaunchKernelGGL(lin_frontend_kernel<96>, grid, dim3(256), 0, st, img, y, N, H, W);
+    else hipLaunchKernelGGL(lin_frontend_kernel<93>, grid, dim3(256), 0, st, img, y, N, H, W);
+    return shdr::check_launch("lin_frontend");
+  }
+  const dim3 grid((unsigned)((W + 63) / 64), (unsigned)(N * H));
+  if (y_channels == 96) hipLaunchKernelGGL(lin_frontend_rows_kernel<96>, grid, dim3(256), 0, st, img, y, N, H, W);
+  else hipLaunchKernelGGL(lin_frontend_rows_kernel<93>, grid, dim3(256), 0, st, img, y, N, H, W);
   return shdr::check_launch("lin_frontend");
 }
