@@ -49,6 +49,7 @@ struct ConvArgs {
   int no_dma;      // force the register-staged kernel (SHDR_ALGO_MFMA_REG)
   int cout_valid;  // channels actually stored (<= Cout; the filter may be zero-padded to Cout)
   int prec;        // 0: exact fp32 MFMA; 1: fp16 / 2: bf16 MFMA operands (fp32 in HBM and LDS, fp32 accumulate)
+  int legacy_epilogue;   // SHDR_CONV_LEGACY_EPILOGUE: store straight from the accumulator layout (comparison)
 };
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -124,6 +125,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         }
       }
     }
+  }
+}
+
+// Row-contiguous epilogue for the LDS-DMA kernel (BN >= 32, every output channel stored): in the MFMA accumulator layout a
+// lane holds 4 couts of one pixel, so a wave store instruction writes 64-byte pieces at a stride of Cout*4 bytes -- the
+// output-bound layers (1x1 convs with few input channels, the 4 -> 64 image layers) ran at 1.0-1.4 TB/s of stores.  Here the
+// block's 128 x BN tile is staged through LDS (the pipeline buffers are dead), and each thread then owns consecutive 16-byte
+// pieces of one pixel row: a wave instruction writes 1 KiB made of BN*4-byte contiguous runs, and bias / scale / shift /
+// residual are read the same coalesced way.
+template <int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&acc)[MT][NT], float* stage, int img, int oh0,
+                                                     int ow0, int n0, int wm, int wn, int fi, int fg, int tid) {
+  constexpr int RS = BN + 4;                           // row stride in floats (16-byte aligned, rows land on shifted banks)
+  __syncthreads();                                     // every wave is done with the pipeline buffers
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int r = wm * MT * 16 + mi * 16 + fi;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+      *reinterpret_cast<f32x4*>(stage + r * RS + wn * NT * 16 + ni * 16 + 4 * fg) = acc[mi][ni];
+  }
+  __syncthreads();
+  constexpr int QR = BN / 4;                           // float4 per tile row
+  constexpr int TOTAL = BM * QR;
+#pragma unroll 4
+  for (int e = tid; e < TOTAL; e += 256) {
+    const int r = e / QR, q = e - r * QR;
+    const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
+    if (oh >= a.Ho || ow >= a.Wo) continue;
+    const int co = n0 + 4 * q;
+    const size_t pix = ((size_t)img * a.Ho + oh) * a.Wo + ow;
+    float4 v = *reinterpret_cast<const float4*>(stage + r * RS + 4 * q);
+    if (a.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    }
+    if (a.act1 != SHDR_ACT_NONE) {
+      v.x = shdr::act_apply(v.x, a.act1); v.y = shdr::act_apply(v.y, a.act1);
+      v.z = shdr::act_apply(v.z, a.act1); v.w = shdr::act_apply(v.w, a.act1);
+    }
+    if (a.scale) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.scale + co);
+      const float4 t4 = *reinterpret_cast<const float4*>(a.shift + co);
+      v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
+    }
+    if (a.res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(a.res + pix * a.res_cs + co);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (a.act2 != SHDR_ACT_NONE) {
+      v.x = shdr::act_apply(v.x, a.act2); v.y = shdr::act_apply(v.y, a.act2);
+      v.z = shdr::act_apply(v.z, a.act2); v.w = shdr::act_apply(v.w, a.act2);
+    }
+    *reinterpret_cast<float4*>(a.y + pix * a.y_cs + co) = v;
   }
 }
 
@@ -339,7 +394,11 @@ typedef __attribute__((address_space(1))) const void* shdr_gptr_t;
 typedef __attribute__((address_space(3))) void* shdr_lptr_t;
 
 template <int BM, int BN>
-__host__ __device__ constexpr int conv_dma_lds_bytes() { return 2 * (BM * BK + BK * BN) * 4; }
+__host__ __device__ constexpr int conv_dma_lds_bytes() {
+  constexpr int pipe = 2 * (BM * BK + BK * BN) * 4;
+  constexpr int stage = BN >= 32 ? BM * (BN + 4) * 4 : 0;       // output tile staged for row-contiguous stores (BN >= 32)
+  return pipe > stage ? pipe : stage;
+}
 
 //   * PREC = 1 / 2 (fp16 / bf16 MFMA operands, BASELINE configs[4]): the LDS image stays fp32 -- the same DMA,
 //     the same fragment reads -- and the 8 k values a lane group owns in a chunk (4g..4g+3, 16+4g..16+4g+3)
@@ -582,6 +641,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_dma_kernel(const ConvArgs a)
   }
   compute_chunk((a.nchunks - 1) & 1, std::false_type{});
 
+  if constexpr (BN >= 32) {
+    if (a.cout_valid == a.Cout && !a.legacy_epilogue) {           // block-uniform
+      conv_epilogue_staged<BM, BN, MT, NT>(a, acc, smem, img, oh0, ow0, n0, wm, wn, fi, fg, tid);
+      return;
+    }
+  }
   conv_epilogue<MT, NT>(a, acc, img, oh0, ow0, n0, wm, wn, fi, fg);
 }
 
@@ -990,6 +1055,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   a.res_cs = d->res_cstride; a.y_cs = y_cs; a.cout_valid = cout_valid;
   a.w_bstride = d->w_batch_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  a.legacy_epilogue = getenv("SHDR_CONV_LEGACY_EPILOGUE") != nullptr;
 
   const bool ragged = (cout_valid % 4) != 0;  // scalar epilogue: no alignment demands on y/res/bias
   const bool mfma_ok = (a.C1 % 4 == 0) && (a.C2 % 4 == 0) && (a.Cout % 16 == 0) &&
