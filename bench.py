@@ -185,122 +185,130 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
     if rank == 0 and not args.no_roofline:
-        records = []     # (kernel label, flops, e0, e1, description, nested)
-        orig = K.conv2d
-        depth = [0]
-
-        def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            wino = None
-            if (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
-                    and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}):
-                wino = K.winograd_path(w.shape[2], w.shape[3])
-            e0.record()
-            depth[0] += 1
-            try:
-                y = orig(x, w, bias, stride=stride, x2=x2, **kw)
-            finally:
-                depth[0] -= 1
-            e1.record()
-            label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
-                     "winograd_fused_kernel" if wino == "fused" else conv_variant(w, x, x2, kw.get("algo", 0), stride))
-            records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
-                            "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
-                                                        0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),
-                            depth[0] > 0))
-            return y
-
-        reps = 3
-        eager(ldr)           # the caching allocator's pool of THIS stream (the timed leg may have run on side streams)
-        torch.cuda.synchronize()
-        K.conv2d = timed_conv
         try:
-            for _ in range(reps):
-                eager(ldr)
+            records = []     # (kernel label, flops, e0, e1, description, nested)
+            orig = K.conv2d
+            depth = [0]
+
+            def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                wino = None
+                if (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+                        and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}):
+                    wino = K.winograd_path(w.shape[2], w.shape[3])
+                e0.record()
+                depth[0] += 1
+                try:
+                    y = orig(x, w, bias, stride=stride, x2=x2, **kw)
+                finally:
+                    depth[0] -= 1
+                e1.record()
+                label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
+                         "winograd_fused_kernel" if wino == "fused" else conv_variant(w, x, x2, kw.get("algo", 0), stride))
+                records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
+                                "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
+                                                            0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),
+                                depth[0] > 0))
+                return y
+
+            reps = 3
+            eager(ldr)           # the caching allocator's pool of THIS stream (the timed leg may have run on side streams)
             torch.cuda.synchronize()
-        finally:
-            K.conv2d = orig
-        # one entry per conv call of ONE pass, timed as the median over the `reps` passes (a host-side hiccup --
-        # e.g. the runtime growing its signal pool inside hipEventRecord -- shows up as GPU idle time between
-        # the two events of whichever call it hits, in one pass only)
-        per_pass = len(records) // reps
-        calls = []
-        for i in range(per_pass):
-            var, fl, _, _, desc, nested = records[i]
-            ms = sorted(records[i + r * per_pass][2].elapsed_time(records[i + r * per_pass][3]) for r in range(reps))[reps // 2]
-            calls.append((var, fl, ms * 1e-3, desc, nested))
-        if args.layers:
-            for var, fl, sec, desc, nested in calls:
-                print("%-46s %-28s %8.3f ms %7.2f TF%s" % (var, desc, sec * 1e3, fl / sec / 1e12,
-                                                         "  (nested GEMM, executed FLOPs)" if nested else ""), file=sys.stderr)
-        # layers: top-level calls with the reference layer's algorithmic FLOPs; kernels: every launch of a conv
-        # kernel (top-level direct convs + the GEMMs nested in Winograd layers, with the FLOPs they execute)
-        layers, agg = {}, {}
-        for var, fl, sec, _, nested in calls:
-            if not nested:
-                a = layers.setdefault(var, [0.0, 0.0, 0])
-                a[0] += fl; a[1] += sec; a[2] += 1
-            if nested or not var.startswith("winograd_f2x2"):
-                a = agg.setdefault(var, [0.0, 0.0, 0])
-                # per KERNEL the MFMA FLOPs it executes: the fused Winograd kernel runs 16 / 36 of the layer's direct-form FLOPs
-                a[0] += fl / 2.25 if var == "winograd_fused_kernel" else fl
-                a[1] += sec; a[2] += 1
-        reps = 1             # `calls` holds one pass
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, sec, cnt = agg[dom]
-        achieved = fl / sec / 1e12
-        conv_total_flops = sum(a[0] for a in layers.values()) / reps
-        conv_total_sec = sum(a[1] for a in layers.values()) / reps
-        # HBM bytes per launch of the dominant kernel: PMC counters collected offline (rocprofv3 cannot profile
-        # the process it runs in) with the same workload -- see profiles/r01_traffic.json for the recipe
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tk = json.load(f)["kernels"]
-            if dom.startswith("conv_mfma"):
-                key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
-                hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
-            else:
-                hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(dom)]
-            traffic = hits[0] if hits else None
-        except (OSError, KeyError, ValueError):
-            pass
-        result["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
-            "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
-            "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
-            "flop_convention": "MFMA FLOPs the kernel executes (Winograd kernels: layer FLOPs / 2.25); per_layer_path holds the "
-                               "reference layers' direct-form (algorithmic) FLOPs",
-            "all_conv": {"tflops": round(conv_total_flops / conv_total_sec / 1e12, 2),
-                         "ms_per_step": round(conv_total_sec * 1e3, 3),
-                         "gflop_per_step": round(conv_total_flops / 1e9, 1)},
-            "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
-                               "launches_per_step": v[2] // reps} for k, v in sorted(agg.items())},
-            "per_layer_path": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
-                                   "layers_per_step": v[2] // reps} for k, v in sorted(layers.items())},
-        }
+            K.conv2d = timed_conv
+            try:
+                for _ in range(reps):
+                    eager(ldr)
+                torch.cuda.synchronize()
+            finally:
+                K.conv2d = orig
+            # one entry per conv call of ONE pass, timed as the median over the `reps` passes (a host-side hiccup --
+            # e.g. the runtime growing its signal pool inside hipEventRecord -- shows up as GPU idle time between
+            # the two events of whichever call it hits, in one pass only)
+            per_pass = len(records) // reps
+            calls = []
+            for i in range(per_pass):
+                var, fl, _, _, desc, nested = records[i]
+                ms = sorted(records[i + r * per_pass][2].elapsed_time(records[i + r * per_pass][3]) for r in range(reps))[reps // 2]
+                calls.append((var, fl, ms * 1e-3, desc, nested))
+            if args.layers:
+                for var, fl, sec, desc, nested in calls:
+                    print("%-46s %-28s %8.3f ms %7.2f TF%s" % (var, desc, sec * 1e3, fl / sec / 1e12,
+                                                             "  (nested GEMM, executed FLOPs)" if nested else ""), file=sys.stderr)
+            # layers: top-level calls with the reference layer's algorithmic FLOPs; kernels: every launch of a conv
+            # kernel (top-level direct convs + the GEMMs nested in Winograd layers, with the FLOPs they execute)
+            layers, agg = {}, {}
+            for var, fl, sec, _, nested in calls:
+                if not nested:
+                    a = layers.setdefault(var, [0.0, 0.0, 0])
+                    a[0] += fl; a[1] += sec; a[2] += 1
+                if nested or not var.startswith("winograd_f2x2"):
+                    a = agg.setdefault(var, [0.0, 0.0, 0])
+                    # per KERNEL the MFMA FLOPs it executes: the fused Winograd kernel runs 16 / 36 of the layer's direct-form FLOPs
+                    a[0] += fl / 2.25 if var == "winograd_fused_kernel" else fl
+                    a[1] += sec; a[2] += 1
+            reps = 1             # `calls` holds one pass
+            dom = max(agg, key=lambda k: agg[k][1])
+            fl, sec, cnt = agg[dom]
+            achieved = fl / sec / 1e12
+            conv_total_flops = sum(a[0] for a in layers.values()) / reps
+            conv_total_sec = sum(a[1] for a in layers.values()) / reps
+            # HBM bytes per launch of the dominant kernel: PMC counters collected offline (rocprofv3 cannot profile
+            # the process it runs in) with the same workload -- see profiles/r01_traffic.json for the recipe
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                    tk = json.load(f)["kernels"]
+                if dom.startswith("conv_mfma"):
+                    key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
+                    hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
+                else:
+                    hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(dom)]
+                traffic = hits[0] if hits else None
+            except (OSError, KeyError, ValueError):
+                pass
+            result["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+                "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
+                "flop_convention": "MFMA FLOPs the kernel executes (Winograd kernels: layer FLOPs / 2.25); per_layer_path holds the "
+                                   "reference layers' direct-form (algorithmic) FLOPs",
+                "all_conv": {"tflops": round(conv_total_flops / conv_total_sec / 1e12, 2),
+                             "ms_per_step": round(conv_total_sec * 1e3, 3),
+                             "gflop_per_step": round(conv_total_flops / 1e9, 1)},
+                "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
+                                   "launches_per_step": v[2] // reps} for k, v in sorted(agg.items())},
+                "per_layer_path": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / reps * 1e3, 3),
+                                       "layers_per_step": v[2] // reps} for k, v in sorted(layers.items())},
+            }
+        except Exception as exc:      # an auxiliary leg must never cost the headline line
+            result['roofline_error'] = repr(exc)[:300]
+
 
     # ---- CPU baseline: the float32 NumPy oracle ("port") on a bounded sample, rank 0, N=1 only ------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        from oracle import nets  # checker / baseline only -- never on the product path
-        table = np.load(os.path.join(ROOT, "singlehdr-tf2_amd", "data", "invemor_g0_hinv11.npy"))
-        params = {k: {n: t.cpu().numpy() for n, t in m.state_dict().items()}
-                  for k, m in (("deq", deq), ("lin", lin), ("hal", hal))}
-        sample = ldr[:1].cpu().numpy()
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        torch.set_num_threads(cores)
-        t0 = time.perf_counter()
-        ref = nets.inference(params, sample, table, with_refinement=False)["A_pred"]
-        cpu_dt = time.perf_counter() - t0
-        err = float(np.abs(out[:1].cpu().numpy() - ref).max() / np.abs(ref).max())
-        result["cpu_baseline"] = {
-            "value": round(1.0 / cpu_dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1 image %dx%d deq+lin+hal, float32 NumPy/BLAS oracle (proxy for TF2-CPU, which is not "
-                      "installable here), %.1f s" % (args.size, args.size, cpu_dt),
-            "gpu_vs_oracle_rel_err": float("%.3g" % err),
-        }
+        try:
+            from oracle import nets  # checker / baseline only -- never on the product path
+            table = np.load(os.path.join(ROOT, "singlehdr-tf2_amd", "data", "invemor_g0_hinv11.npy"))
+            params = {k: {n: t.cpu().numpy() for n, t in m.state_dict().items()}
+                      for k, m in (("deq", deq), ("lin", lin), ("hal", hal))}
+            sample = ldr[:1].cpu().numpy()
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            torch.set_num_threads(cores)
+            t0 = time.perf_counter()
+            ref = nets.inference(params, sample, table, with_refinement=False)["A_pred"]
+            cpu_dt = time.perf_counter() - t0
+            err = float(np.abs(out[:1].cpu().numpy() - ref).max() / np.abs(ref).max())
+            result["cpu_baseline"] = {
+                "value": round(1.0 / cpu_dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": "1 image %dx%d deq+lin+hal, float32 NumPy/BLAS oracle (proxy for TF2-CPU, which is not "
+                          "installable here), %.1f s" % (args.size, args.size, cpu_dt),
+                "gpu_vs_oracle_rel_err": float("%.3g" % err),
+            }
+        except Exception as exc:      # an auxiliary leg must never cost the headline line
+            result['cpu_baseline_error'] = repr(exc)[:300]
+
 
     # ---- joint-training leg (BASELINE configs[3]): deq+lin+hal + VGG16 perceptual loss, fwd+bwd+Adam, batch 32 x
     #      256x256 per GPU, ONE RCCL all-reduce(SUM) of the flat fp32 gradient per step (weak scaling) ------------
