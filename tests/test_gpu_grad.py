@@ -45,6 +45,9 @@ CONV_GRAD_CASES = [
     ("wino_wgrad_ragged_64_64", 2, 13, 19, 64, 0, 64, 3, 1, 2, 1.0),          # Winograd-domain wgrad: odd H, W % 16 != 0
     ("wino_wgrad_concat_64_64_to_128", 1, 18, 34, 64, 64, 128, 3, 1, 1, 0.5),   # two sources, x2 scale
     ("wino_wgrad_256_64_many_units", 3, 32, 48, 256, 0, 64, 3, 1, 0, 1.0),
+    ("wino_wgrad_512_512_deep", 2, 16, 16, 512, 0, 512, 3, 1, 1, 1.0),        # the widest layers of the Hallucination-Net
+    ("alltaps_wgrad_32_16_ragged", 2, 11, 37, 32, 0, 16, 3, 1, 2, 1.0),        # all-taps narrow wgrad, W % 32 != 0
+    ("alltaps_wgrad_16_32_5x5", 1, 20, 33, 16, 0, 32, 5, 1, 2, 1.0),
 ]
 
 

@@ -294,7 +294,7 @@ def test_conv2d_winograd_parity(shdr, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 13, 18, 32, 64), (1, 8, 16, 256, 64), (3, 6, 4, 8, 64),
-                                   (1, 21, 37, 72, 192), (2, 32, 32, 128, 64)])
+                                   (1, 21, 37, 72, 192), (2, 32, 32, 128, 64), (1, 16, 16, 512, 512)])
 def test_conv2d_winograd_fused_parity(shdr, shape):
     """One-kernel Winograd F(2x2,3x3) (operands built per lane from the raw patch in LDS) vs the float64 oracle: ragged
     tiles (H % 8, W % 16 != 0, image smaller than one block tile), Cin a multiple of 8 only, the fused epilogue."""
