@@ -44,14 +44,35 @@ def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
     if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
         return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=cv), x_shape)
     if stride == 2:
-        # general stride 2 (the 7x7/2 first conv of the Linearization-Net in the fine-tuning chain):
-        # zero-insert dz to the input grid, then a stride-1 conv with the flipped filter and the
-        # transposed padding k-1-pad (the forward SAME pad is asymmetric: 2 before / 3 after)
+        # general stride 2 (the 7x7/2 first conv of the Linearization-Net in the fine-tuning chain), polyphase form: the
+        # input pixels of parity (p, q) only see the filter taps of one parity, so dx[:, p::2, q::2] is a stride-1
+        # correlation of dz with the sub-filter wt[a0::2, b0::2] of the flipped filter -- 4 small convs with together exactly
+        # the forward's FLOPs, instead of one k x k conv over a zero-inserted dz (4x the FLOPs, 3/4 of them on zeros)
         n, h, wd, _ = x_shape
-        ho, pt = K.same_pad(h, kh, 2)
-        wo, pl = K.same_pad(wd, kw, 2)
-        up = K.upsample_zero2(dz, (n, 2 * ho, 2 * wo, dz.shape[3]))
-        return K.conv2d(up, wt, cout_valid=c_count, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(h, wd))
+        _, pt = K.same_pad(h, kh, 2)
+        _, pl = K.same_pad(wd, kw, 2)
+        dx = torch.empty((n, h, wd, c_count), device=dz.device, dtype=torch.float32)
+
+        def phase(par_in, pad_fwd, k):
+            par = (par_in + pad_fwd) % 2                      # parity of the taps this input parity sees
+            taps = len(range(par, k, 2))
+            off = (par_in + pad_fwd - par) // 2
+            return k - 1 - par - 2 * (taps - 1), taps - 1 - off, taps      # first index into the flipped filter, pad, taps
+        for p_ in range(2):
+            a0, pad_t, th = phase(p_, pt, kh)
+            mh = (h - p_ + 1) // 2
+            for q_ in range(2):
+                b0, pad_l, tw = phase(q_, pl, kw)
+                mw = (wd - q_ + 1) // 2
+                if mh == 0 or mw == 0:
+                    continue
+                if th == 0 or tw == 0:
+                    dx[:, p_::2, q_::2] = 0.0
+                    continue
+                sub = wt[a0::2, b0::2].contiguous()
+                dx[:, p_::2, q_::2] = K.conv2d(dz, sub, cout_valid=c_count if cout_pad else None, pad=(pad_t, pad_l),
+                                               out_hw=(mh, mw))
+        return dx
     raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built" % (kh, kw, stride))
 
 

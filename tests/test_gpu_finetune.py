@@ -36,10 +36,12 @@ def test_frontend_backward_parity(shdr):
 
 
 def test_strided_7x7_dgrad_parity(shdr):
+    """polyphase input gradient of stride-2 convolutions: even and odd sizes (the SAME padding changes with the parity of
+    the size), 7x7 (Linearization-Net conv1), 5x5 and 3x3"""
     rng = np.random.default_rng(2)
-    for h, w in ((16, 16), (14, 18)):
+    for h, w, k in ((16, 16, 7), (14, 18, 7), (15, 17, 7), (13, 16, 5), (12, 11, 3), (2, 2, 7)):
         x = f32(rng.normal(size=(2, h, w, 32)))
-        wt = f32(rng.normal(size=(7, 7, 32, 64)) / 40)
+        wt = f32(rng.normal(size=(k, k, 32, 64)) / 40)
         gy = f32(rng.normal(size=(2, (h + 1) // 2, (w + 1) // 2, 64)))
         tx, tw = R.T(x, True), R.T(wt, True)
         (R.conv2d(tx, tw, None, 2) * R.T(gy)).sum().backward()
