@@ -160,6 +160,23 @@ def main():
                    "parallelism": "batch-sharded x%d, no collective" % n_gpus},
     }
 
+    # ---- BASELINE configs[1]: Dequantization-Net only, batch 8 x 512 x 512 (informational; the headline stays configs[2]) ----
+    if not args.no_refinement:
+        x8 = ldr[:8].contiguous() if args.batch >= 8 else ldr
+        with torch.no_grad():
+            for _ in range(2):
+                deq(x8, training=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                deq(x8, training=False)
+            torch.cuda.synchronize()
+        ddt = (time.perf_counter() - t0) / args.steps
+        result["deq_only"] = {"workload": "BASELINE configs[1]: Dequantization-Net forward, batch=%d x %dx%d, one GPU"
+                                          % (x8.shape[0], args.size, args.size),
+                              "ms_per_step": round(ddt * 1e3, 3), "images_per_s": round(x8.shape[0] / ddt, 2),
+                              "tflops_algorithmic": round(37.83 * (args.size / 512.0) ** 2 * x8.shape[0] / ddt / 1e3, 2)}
+
     # ---- the same inference with the Refinement-Net appended ("report with and without") ----------
     if not args.no_refinement:
         torch.manual_seed(4321)
