@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void conv_rega_kernel(const ConvArgs a) {
       }
     } else {
       // (an explicit next-tap register prefetch measured 5-10 % slower than leaving the schedule to the compiler and the
-      //  8-12 resident waves per CU)
+      //  8-12 resident waves per CU; the same holds for a double-buffered strip in the KK != 0 branch above)
       for (int kh = 0; kh < a.KH; ++kh) {
         for (int kw = 0; kw < a.KW; ++kw) {
           const int iw = iw0 + kw;
@@ -957,8 +957,18 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_lds = lds;
   }
-  const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);          // resident blocks per CU (LDS-limited)
-  long grid = 256L * per_cu;
+  // persistent grid = the blocks that are actually co-resident (VGPR- or LDS-limited): a grid that is not a multiple of the
+  // residency runs its last blocks alone at low occupancy (measured: 768 blocks with 2 resident per CU cost +20 %)
+  static int occ_lds = -1, occ = 0;
+  if (lds != occ_lds) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT, KK>), 256, lds);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    occ = nb > 8 ? 8 : nb;
+    occ_lds = lds;
+  }
+  long grid = 256L * occ;
+  if (const char* e = getenv("SHDR_REGA_PER_CU")) grid = 256L * atoi(e);
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((conv_rega_kernel<MT, NT, CT, KK>), dim3((unsigned)grid), dim3(256), lds, st, a);
   return shdr::check_launch("conv_rega_kernel");

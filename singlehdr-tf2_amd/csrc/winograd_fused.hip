@@ -28,11 +28,14 @@
 // vgg16.py:72-83, dequantization_net.py:35-46 for the 3x3 stride-1 layers).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "shdr_internal.h"
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   constexpr int MT = G::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;                         // [4][RAW_FLOATS]
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)raw;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     raw_off[j] = raw_ok[j] ? ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.Cin + 4u * quad : 0u;
   }
   // B operands: this lane's 16 filter values of a chunk = four float4 at up[(c*4 + j)*256], j = 2*x2 + s, .xyzw = nt 0..3
-  const float* up = a.u + ((size_t)(pn * 8 + wave) * nch * 256 + lane) * 4;
+  const float* ub = a.u + (size_t)(pn * 8 + wave) * nch * 1024;     // wave-uniform: SGPR base, the lane offset stays 32-bit
   auto dma_raw = [&](int c, int buf) {
 #pragma unroll
     for (int j = 0; j < RJ; ++j) {
@@ -149,24 +153,43 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   // Every LDS read precedes the DMA issue of its iteration (see the header).  Counted waits: "s_waitcnt vmcnt(RJ)" before the
   // MFMAs = everything but this iteration's RJ raw DMAs has arrived (the filter registers AND raw(c+2), so the barrier at the
   // end needs no wait of its own and the DMA of raw(c+3) plus the 4 filter loads stay in flight across it).
-  float4 bq[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const float4*>(up + j * 256);
+  // The filter loads are inline asm as well: the compiler's own wait for a register loaded in the PREVIOUS iteration is
+  // vmcnt(0) (its loop-carried scoreboard is conservative), which would drain raw(c+3) in front of the first MFMA group.
+  // Untracked, the only waits are the counted ones written below.
+  f32x4 bq[4];
+  const unsigned ulb = 16u * (unsigned)lane;
+#define WF_LOAD_BQ(J, BASE) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #J "*1024" : "=v"(bq[J]) : "v"(ulb), "s"(BASE))
+  WF_LOAD_BQ(0, ub); WF_LOAD_BQ(1, ub); WF_LOAD_BQ(2, ub); WF_LOAD_BQ(3, ub);
   dma_raw(0, 0);
   dma_raw(nch > 1 ? 1 : 0, 1);
   dma_raw(nch > 2 ? 2 : nch - 1, 2);
   __syncthreads();
 
-  float2 d[MT][2][3];
+  f32x2 d[MT][2][3];
   float2 v[2][MT];                            // [x2][mt]
+  // The patch reads are inline asm: the compiler orders every LDS read it knows of behind ALL LDS-DMA writes in flight
+  // (s_waitcnt vmcnt(0) at the top of the loop -- it cannot tell the four buffers apart), which drained the raw DMA and
+  // the filter reloads once per chunk.  Hidden in asm the reads cost no vmcnt; their own completion is the explicit
+  // "s_waitcnt lgkmcnt(0)" + register fence in patch_ready() before the transform.
   auto read_patch = [&](int buf) {
-    const float* rp = raw + buf * G::RAW_FLOATS;
+    const unsigned base = lds0 + (unsigned)(buf * G::RAW_FLOATS * 4);       // LDS byte address of the buffer
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const unsigned ad = base + (unsigned)a_addr[mt][rr] * 4u;
+        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:16\n\tds_read_b64 %2, %3 offset:32"
+                     : "=&v"(d[mt][rr][0]), "=&v"(d[mt][rr][1]), "=&v"(d[mt][rr][2]) : "v"(ad));
+      }
+  };
+  auto patch_ready = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) only
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d[mt][rr][k] = *reinterpret_cast<const float2*>(rp + a_addr[mt][rr] + k * 4);
+        asm volatile("" : "+v"(d[mt][rr][0]), "+v"(d[mt][rr][1]), "+v"(d[mt][rr][2]));
   };
   auto transform = [&]() {
 #pragma unroll
@@ -187,6 +210,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     }
   };
   read_patch(0);
+  patch_ready();
   transform();
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
@@ -194,34 +218,39 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     __builtin_amdgcn_sched_barrier(0);
     dma_raw(c + 3 < nch ? c + 3 : nch - 1, (c + 3) & 3);      // unconditional: a uniform vmcnt
     __builtin_amdgcn_sched_barrier(0);
-    const float* un = up + (size_t)(c + 1 < nch ? c + 1 : c) * 1024;       // next chunk's operands (the last chunk reloads itself)
-    __builtin_amdgcn_s_waitcnt(0x0F70 | RJ);
-#pragma unroll
-    for (int x2 = 0; x2 < 2; ++x2) {
-      const float b0[4] = {bq[2 * x2].x, bq[2 * x2].y, bq[2 * x2].z, bq[2 * x2].w};
-      const float b1[4] = {bq[2 * x2 + 1].x, bq[2 * x2 + 1].y, bq[2 * x2 + 1].z, bq[2 * x2 + 1].w};
+    const float* un = ub + (size_t)(c + 1 < nch ? c + 1 : c) * 1024;       // next chunk's operands (the last chunk reloads itself)
+    // Four groups of 2*MT*... MFMAs, one per filter register quad j = 2*x2 + k-step.  In flight before group j, oldest first:
+    //   [raw(c+2)] [bq j] [the three quads after j: reloads of this or the previous iteration] [raw(c+3)]
+    // so "vmcnt(RJ + 3)" = quad j (and raw(c+2)) has landed, everything newer stays in flight.  The MFMA builtin is a pure
+    // function of its registers and instruction selection floats it over every chained instruction (all 32 MFMAs ended up
+    // above the waits and reloads: the reloads then sat right in front of the barrier and their L2 latency was exposed in
+    // every chunk); the empty asm statements tie the group to its place: operands are "produced" after the wait, accumulators
+    // are "consumed" before the reload of the quad the group has just read.
+    auto group = [&](auto jc) {
+      constexpr int j = decltype(jc)::value, x2 = j >> 1;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (RJ + 3));
+      asm volatile("" : "+v"(bq[j]));
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].x, b0[nt], acc[x2][mt][nt], 0, 0, 0);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x2][mt].y, b1[nt], acc[x2][mt][nt], 0, 0, 0);
+          acc[x2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((j & 1) ? v[x2][mt].y : v[x2][mt].x, bq[j][nt], acc[x2][mt][nt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      // the MFMAs above have read their B registers: refill them for the next chunk straight from L2 (no LDS, no DMA)
-      __builtin_amdgcn_sched_barrier(0);
-      bq[2 * x2] = *reinterpret_cast<const float4*>(un + (2 * x2) * 256);
-      bq[2 * x2 + 1] = *reinterpret_cast<const float4*>(un + (2 * x2 + 1) * 256);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        asm volatile("" : "+v"(acc[x2][mt][0]), "+v"(acc[x2][mt][1]), "+v"(acc[x2][mt][2]), "+v"(acc[x2][mt][3]));
+    };
+    group(std::integral_constant<int, 0>{}); WF_LOAD_BQ(0, un);
+    group(std::integral_constant<int, 1>{}); WF_LOAD_BQ(1, un);
+    group(std::integral_constant<int, 2>{}); WF_LOAD_BQ(2, un);
+    group(std::integral_constant<int, 3>{}); WF_LOAD_BQ(3, un);
+    patch_ready();
     transform();                              // V(c+1)
     __builtin_amdgcn_s_barrier();
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);        // drain the tail DMA / loads before the pipeline buffers become the M overlay
+  asm volatile("" :: "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]));      // the filter registers stay allocated until their last (unused) reload has landed
   __syncthreads();
 
   // ---- epilogue in two 32-cout passes ---------------------------------------------------------------------------------
