@@ -331,6 +331,7 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
     (2, 17, 31, 32, 0, 16, 3, None),     # u1.conv1
     (2, 16, 20, 16, 16, 16, 3, None),    # u1.conv2: concatenated sources
     (1, 24, 16, 16, 0, 16, 3, 3),        # output head: 3 of 16 padded couts stored
+    (2, 21, 34, 4, 0, 64, 3, None),      # VGG-shaped conv1_1 (Hallucination-Net, VGG16) on the 3-channel image padded to 4
     (1, 8, 8, 8, 0, 16, 3, None)])
 def test_conv2d_register_a_kernel_parity(shdr, shape):
     """conv_rega_kernel (narrow U-Net layers: activations global -> VGPR, filter resident in LDS) vs the float64 oracle and,
