@@ -294,7 +294,8 @@ def test_conv2d_winograd_parity(shdr, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 13, 18, 32, 64), (1, 8, 16, 256, 64), (3, 6, 4, 8, 64),
-                                   (1, 21, 37, 72, 192), (2, 32, 32, 128, 64), (1, 16, 16, 512, 512)])
+                                   (1, 21, 37, 72, 192), (2, 32, 32, 128, 64), (1, 16, 16, 512, 512),
+                                   (1, 9, 17, 16, 64), (2, 10, 33, 24, 128)])     # 2 / 3 chunks: shorter than the 4-deep pipeline
 def test_conv2d_winograd_fused_parity(shdr, shape):
     """One-kernel Winograd F(2x2,3x3) (operands built per lane from the raw patch in LDS) vs the float64 oracle: ragged
     tiles (H % 8, W % 16 != 0, image smaller than one block tile), Cin a multiple of 8 only, the fused epilogue."""
@@ -320,6 +321,23 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
         assert torch.equal(K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU), y)
     with pytest.raises(ValueError, match="Cout"):
         K.winograd_filter_packed(dev(np.ascontiguousarray(wt[..., :48])))
+
+
+def test_conv2d_winograd_fused_tall_tile(shdr, monkeypatch):
+    """the 16 x 16-pixel block tile of the fused kernel (experiment switch SHDR_WINOGRAD_TILE=16: one block per CU, 128
+    accumulator registers, two raw DMA instructions per wave and chunk) against the oracle and the default 8 x 16 tile"""
+    rng = np.random.default_rng(77)
+    K = shdr._ops
+    x = f32(rng.normal(size=(2, 19, 35, 40)))
+    wt = f32(rng.normal(size=(3, 3, 40, 64)) / np.sqrt(360))
+    b = f32(rng.normal(size=64))
+    u = K.winograd_filter_packed(dev(wt))
+    y8 = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU)
+    monkeypatch.setenv("SHDR_WINOGRAD_TILE", "16")
+    y16 = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU)
+    monkeypatch.delenv("SHDR_WINOGRAD_TILE")
+    assert rel_err(host(y16), oracle_conv(x, wt, b, act1=1)) <= TOL
+    assert rel_err(host(y16), host(y8)) <= 1e-6
 
 
 @pytest.mark.parametrize("shape", [  # n, h, w, c1, c2, cout, k, cout_valid
