@@ -89,7 +89,10 @@ def conv_variant(w, x, x2, algo, stride=1):
     narrow = (c2 == 0 and c1 in (4, 8, 12, 16)) or (c1 == 16 and c2 == 16)                 # rega_ok() of conv.hip
     if algo == 0 and stride == 1 and cout in (16, 32) and narrow and w.shape[0] * w.shape[1] * (c1 + c2) * cout * 4 <= 100 * 1024:
         return "conv_rega_kernel<%d>" % cout
-    bn = 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
+    if algo == 0 and stride == 1 and cout == 64 and c1 == 4 and c2 == 0 and tuple(w.shape[:2]) == (3, 3):
+        return "conv_rega_kernel<64>"
+    k = w.shape[0] * w.shape[1] * (c1 + c2)
+    bn = 128 if (cout % 128 == 0 and k > 128) else 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
     return "conv_mfma_dma_kernel<128,%d>" % bn
 
 

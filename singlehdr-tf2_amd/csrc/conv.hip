@@ -1087,7 +1087,9 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   if (algo == SHDR_ALGO_MFMA) {
     SHDR_REQUIRE(mfma_ok, SHDR_E_ALIGN,
                  "conv2d: MFMA path needs C1%%4==0, C2%%4==0, Cout%%16==0, 16-byte aligned tensors");
-    if (a.Cout % 128 == 0) return launch_mfma<128, 128, 2, 2>(a, st);
+    // short-K layers (1x1 expansions 64 -> 256, 128 -> 512 of the ResNet blocks) are bound by their output stream: the 128 x 64
+    // tile keeps three blocks per CU in flight instead of two (0.32 -> 0.27 ms with the fused residual, 0.19 -> 0.16 without)
+    if (a.Cout % 128 == 0 && a.K > 128) return launch_mfma<128, 128, 2, 2>(a, st);
     const bool rega = a.prec == 0 && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && getenv("SHDR_NO_REGA") == nullptr;
     if (rega && a.Cout == 64) return launch_rega<4, 4, 4, 3>(a, st);
     if (a.Cout % 64 == 0) return launch_mfma<128, 64, 4, 1>(a, st);

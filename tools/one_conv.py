@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--res", action="store_true", help="fused residual add + BN scale/shift in the epilogue")
     ap.add_argument("--algo", type=int, default=0, help="SHDR_ALGO_* (4: fp16 MFMA operands, 5: bf16)")
     a = ap.parse_args()
     K = importlib.import_module("singlehdr-tf2_amd")._ops
@@ -32,13 +33,15 @@ def main():
     x2 = torch.randn(a.n, a.hw, a.hw, a.c2, device="cuda") if a.c2 else None
     w = torch.randn(a.k, a.k, a.cin + a.c2, a.cout, device="cuda") * 0.02
     b = torch.randn(a.cout, device="cuda")
+    ho0 = -(-a.hw // a.stride)
+    extra = dict(residual=torch.randn(a.n, ho0, ho0, a.cout, device="cuda"), scale=torch.rand(a.cout, device="cuda"), shift=torch.randn(a.cout, device="cuda"), act2=K.ACT_RELU) if a.res else {}
     for _ in range(3):
-        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU, algo=a.algo)
+        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_NONE if a.res else K.ACT_RELU, algo=a.algo, **extra)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(a.reps):
-        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_RELU, algo=a.algo)
+        y = K.conv2d(x, w, b, stride=a.stride, x2=x2, act1=K.ACT_NONE if a.res else K.ACT_RELU, algo=a.algo, **extra)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
