@@ -4,6 +4,8 @@
 // Replaces the GradientTape.gradient / Adam.apply_gradients call sites of
 // joint_training.py:185-186, train.py:175-176,195-196,242-243, finetune_real_dataset.py:177-178
 // for the ops of SURVEY.md section 2.2 rows T3, T5-T8, T12-T18.
+#include <stdlib.h>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -55,11 +57,9 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
                                                            int Q, int act) {
   __shared__ float4 part[256];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nquads; e += (long)gridDim.x * 256) {
-    const float4 g = *reinterpret_cast<const float4*>(dy + 4 * e);
+  auto one = [&](long e, const float4 g, const float4 yv) {
     float4 d = g;
     if (act != SHDR_ACT_NONE) {
-      const float4 yv = *reinterpret_cast<const float4*>(y + 4 * e);
       if (act == SHDR_ACT_RELU) {
         d.x = yv.x > 0.f ? g.x : 0.f; d.y = yv.y > 0.f ? g.y : 0.f; d.z = yv.z > 0.f ? g.z : 0.f; d.w = yv.w > 0.f ? g.w : 0.f;
       } else if (act == SHDR_ACT_LRELU) {
@@ -72,6 +72,25 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
       *reinterpret_cast<float4*>(dz + 4 * e) = d;
     }
     s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+  };
+  // two quads per trip: with the grid capped at 512 blocks one float4 pair per thread keeps only 4 MB in flight
+  const long step = (long)gridDim.x * 256;
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; e + step < nquads; e += 2 * step) {
+    const float4 g0 = *reinterpret_cast<const float4*>(dy + 4 * e), g1 = *reinterpret_cast<const float4*>(dy + 4 * (e + step));
+    float4 y0 = g0, y1 = g1;
+    if (act != SHDR_ACT_NONE) {
+      y0 = *reinterpret_cast<const float4*>(y + 4 * e);
+      y1 = *reinterpret_cast<const float4*>(y + 4 * (e + step));
+    }
+    one(e, g0, y0);
+    one(e + step, g1, y1);
+  }
+  if (e < nquads) {
+    const float4 g0 = *reinterpret_cast<const float4*>(dy + 4 * e);
+    float4 y0 = g0;
+    if (act != SHDR_ACT_NONE) y0 = *reinterpret_cast<const float4*>(y + 4 * e);
+    one(e, g0, y0);
   }
   part[threadIdx.x] = s;
   __syncthreads();
@@ -302,6 +321,84 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
+// The same sums with 16-byte accesses (C % 4 == 0): a thread owns one channel quad (QL = quads per pixel row handled side by
+// side, a power of two <= 256) and walks the pixels two at a time, so two independent float4 loads per operand are in flight
+// (the scalar kernel above runs at 2 TB/s, this one at the rate of a copy).  Double accumulators as above; fp32 only in
+// the products of the loaded values.
+__global__ __launch_bounds__(256) void bn_reduce4_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                         const float* __restrict__ y, const float* __restrict__ mean,
+                                                         double* __restrict__ ws, long npix, int C, int mode) {
+  __shared__ double part[8][256];
+  const int Q = C >> 2;
+  int QL = 1;
+  while (QL < Q && QL < 256) QL <<= 1;
+  const int PL = 256 / QL;
+  const int ql = threadIdx.x % QL, pl = threadIdx.x / QL;
+  for (int q0 = 0; q0 < Q; q0 += QL) {
+    const int q = q0 + ql;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (q < Q) {
+      float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mode) mu = *reinterpret_cast<const float4*>(mean + 4 * q);
+      auto acc = [&](const float4 av, const float4 xv, const float4 yv) {
+        const float g[4] = {av.x, av.y, av.z, av.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float m[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (mode == 0) {
+            const double v = (double)g[e];
+            s1[e] += v; s2[e] += v * v;
+          } else {
+            const float gg = (y && !(yy[e] > 0.f)) ? 0.f : g[e];
+            s1[e] += (double)gg; s2[e] += (double)gg * (double)(xx[e] - m[e]);
+          }
+        }
+      };
+      const long step = (long)gridDim.x * PL;
+      long p = (long)blockIdx.x * PL + pl;
+      const float4 z4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      for (; p + 3 * step < npix; p += 4 * step) {            // four independent loads per operand in flight
+        float4 av[4], xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long i = (p + u * step) * C + 4 * q;
+          av[u] = *reinterpret_cast<const float4*>(a + i);
+          xv[u] = z4; yv[u] = z4;
+          if (mode) {
+            xv[u] = *reinterpret_cast<const float4*>(x + i);
+            if (y) yv[u] = *reinterpret_cast<const float4*>(y + i);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc(av[u], xv[u], yv[u]);
+      }
+      for (; p < npix; p += step) {
+        const long i0 = p * C + 4 * q;
+        const float4 a0 = *reinterpret_cast<const float4*>(a + i0);
+        float4 x0 = z4, y0 = z4;
+        if (mode) {
+          x0 = *reinterpret_cast<const float4*>(x + i0);
+          if (y) y0 = *reinterpret_cast<const float4*>(y + i0);
+        }
+        acc(a0, x0, y0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { part[e][threadIdx.x] = s1[e]; part[4 + e][threadIdx.x] = s2[e]; }
+    __syncthreads();
+    if (pl == 0 && q < Q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double t1 = s1[e], t2 = s2[e];
+        for (int j = 1; j < PL; ++j) { t1 += part[e][j * QL + ql]; t2 += part[4 + e][j * QL + ql]; }
+        atomicAdd(ws + 4 * q + e, t1);
+        atomicAdd(ws + C + 4 * q + e, t2);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // mean/var (biased) from the double sums; optional Keras moving-average update
 // (momentum m: moving = moving*m + batch*(1-m); the variance update uses the unbiased estimate)
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ var,
@@ -356,6 +453,47 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float m1 = (float)(ws[c] / (double)npix);
     const float m2 = (float)(ws[C + c] / (double)npix) * invstd;   // mean(dy' * xhat)
     dx[i] = gamma[c] * invstd * (g - m1 - xh * m2);
+  }
+}
+
+// float4 form (C / 4 a power of two, grid * 256 a multiple of it): a thread's channel quad is fixed over its grid-stride
+// loop, so the per-channel factors (two fp64 divisions, rsqrt) are computed once per thread instead of once per element
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ gamma,
+                                                            const double* __restrict__ ws, float* __restrict__ dx,
+                                                            long nquads, long npix, int C, float eps) {
+  const int Q = C >> 2;
+  const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % Q);
+  float invstd[4], mu[4], m1[4], m2[4], ga[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    invstd[e] = rsqrtf(var[c] + eps);
+    mu[e] = mean[c];
+    m1[e] = (float)(ws[c] / (double)npix);
+    m2[e] = (float)(ws[C + c] / (double)npix) * invstd[e];
+    ga[e] = gamma[c] * invstd[e];
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
+    const float4 g4 = *reinterpret_cast<const float4*>(dy + 4 * i);
+    const float4 x4 = *reinterpret_cast<const float4*>(x + 4 * i);
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
+    if (y) {
+      const float4 y4 = *reinterpret_cast<const float4*>(y + 4 * i);
+      if (!(y4.x > 0.f)) g[0] = 0.f;
+      if (!(y4.y > 0.f)) g[1] = 0.f;
+      if (!(y4.z > 0.f)) g[2] = 0.f;
+      if (!(y4.w > 0.f)) g[3] = 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xx[e] - mu[e]) * invstd[e];
+      o[e] = ga[e] * (g[e] - m1[e] - xh * m2[e]);
+    }
+    *reinterpret_cast<float4*>(dx + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -630,6 +768,26 @@ inline int reduce_grid(long npix, int C) {
   return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
 }
 
+inline void launch_bn_reduce(hipStream_t st, const float* a, const float* x, const float* y, const float* mean, double* ws,
+                             long npix, int C, int mode) {
+  const bool vec = C % 4 == 0 && shdr::aligned16(a) && (!x || shdr::aligned16(x)) && (!y || shdr::aligned16(y)) &&
+                   (!mean || shdr::aligned16(mean)) && getenv("SHDR_BN_SCALAR") == nullptr;
+  if (vec) {
+    const int Q = C / 4;
+    int QL = 1;
+    while (QL < Q && QL < 256) QL <<= 1;
+    const long PL = 256 / QL;
+    long g = (npix + PL * 16 - 1) / (PL * 16);          // >= 16 pixels per thread before the grid is capped
+    // every block ends with 2 fp64 atomics per channel on the SAME addresses: 1024 blocks measured 2x slower than 256 on a
+    // 134 MB tensor (0.111 vs 0.053 ms); the largest tensors want 512
+    const long cap = npix * C >= (1L << 26) ? 512 : 256;
+    g = g < 1 ? 1 : (g > cap ? cap : g);
+    hipLaunchKernelGGL(bn_reduce4_kernel, dim3((unsigned)g), dim3(256), 0, st, a, x, y, mean, ws, npix, C, mode);
+  } else {
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(reduce_grid(npix, C)), dim3(256), 0, st, a, x, y, mean, ws, npix, C, mode);
+  }
+}
+
 }  // namespace
 
 extern "C" int shdr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream) {
@@ -718,8 +876,7 @@ extern "C" int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float*
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_stats: bad shape");
   hipStream_t st = S(stream);
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_stats: memset");
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(reduce_grid(npix, C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, ws,
-                     (long)npix, C, 0);
+  launch_bn_reduce(st, x, nullptr, nullptr, nullptr, ws, (long)npix, C, 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, mean, var, moving_mean, moving_var,
                      (long)npix, C, momentum);
   return shdr::check_launch("bn_stats");
@@ -739,10 +896,20 @@ extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_r
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_bwd: bad shape");
   hipStream_t st = S(stream);
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_bwd: memset");
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(reduce_grid(npix, C)), dim3(256), 0, st, dy, x, y_relu, mean, ws, (long)npix, C, 1);
+  launch_bn_reduce(st, dy, x, y_relu, mean, ws, (long)npix, C, 1);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, var, dgamma, dbeta, C, eps);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(shdr::stream_grid(npix * C)), dim3(256), 0, st, dy, x, y_relu, mean, var,
-                     gamma, ws, dx, (long)npix * C, (long)npix, C, eps);
+  const int Q = C / 4;
+  if (C % 4 == 0 && (Q & (Q - 1)) == 0 && Q <= 4096 && shdr::aligned16(dy) && shdr::aligned16(x) && shdr::aligned16(dx) &&
+      (!y_relu || shdr::aligned16(y_relu)) && getenv("SHDR_BN_SCALAR") == nullptr) {
+    long grid = shdr::stream_grid(npix * Q);
+    const long unit = Q > 256 ? Q / 256 : 1;              // grid * 256 must be a multiple of Q
+    grid = (grid + unit - 1) / unit * unit;
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)grid), dim3(256), 0, st, dy, x, y_relu, mean, var, gamma, ws, dx,
+                       (long)npix * Q, (long)npix, C, eps);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(shdr::stream_grid(npix * C)), dim3(256), 0, st, dy, x, y_relu, mean, var,
+                       gamma, ws, dx, (long)npix * C, (long)npix, C, eps);
+  }
   return shdr::check_launch("bn_bwd");
 }
 
