@@ -492,6 +492,14 @@ int dispatch_n(WgradArgs& a, hipStream_t st) {
   return launch_wgrad<BMc, 16, (BMc >= 64 ? 4 : BMc / 16), 1>(a, st);
 }
 
+// 96 input channels (the 7x7 / 2 stem of the Linearization-Net on the 96-channel frontend tensor): one 96-ci tile instead
+// of three 32-ci tiles -- 52 instead of 94 bytes of LDS-DMA per kFLOP (the 32 x 64 tile sits at the LDS-DMA ceiling)
+int dispatch_n96(WgradArgs& a, hipStream_t st) {
+  if (a.Cout % 128 == 0) return launch_wgrad<96, 128, 2, 2>(a, st);
+  if (a.Cout % 64 == 0) return launch_wgrad<96, 64, 2, 2>(a, st);
+  return launch_wgrad<96, 32, 2, 2>(a, st);
+}
+
 }  // namespace
 
 extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, int which, const float* dz,
@@ -531,6 +539,7 @@ extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, 
   if (mfma_ok && d->algo != SHDR_ALGO_DIRECT) {
     if (a.Cx % 128 == 0) return dispatch_n<128>(a, st);
     if (a.Cx % 64 == 0) return dispatch_n<64>(a, st);
+    if (a.Cx % 96 == 0 && a.Cout % 32 == 0 && getenv("SHDR_NO_WGRAD96") == nullptr) return dispatch_n96(a, st);
     if (a.Cx % 32 == 0) return dispatch_n<32>(a, st);
     return dispatch_n<16>(a, st);
   }

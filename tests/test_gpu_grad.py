@@ -48,6 +48,9 @@ CONV_GRAD_CASES = [
     ("wino_wgrad_512_512_deep", 2, 16, 16, 512, 0, 512, 3, 1, 1, 1.0),        # the widest layers of the Hallucination-Net
     ("alltaps_wgrad_32_16_ragged", 2, 11, 37, 32, 0, 16, 3, 1, 2, 1.0),        # all-taps narrow wgrad, W % 32 != 0
     ("alltaps_wgrad_16_32_5x5", 1, 20, 33, 16, 0, 32, 5, 1, 2, 1.0),
+    ("stem_96_64_7x7_s2", 2, 34, 30, 96, 0, 64, 7, 2, 1, 1.0),              # Linearization-Net stem: the 96-ci wgrad tile
+    ("c96_32_1x1_tile96", 1, 24, 24, 96, 0, 32, 1, 1, 0, 1.0),
+    ("c96_128_5x5_tile96", 1, 12, 20, 96, 0, 128, 5, 1, 2, 1.0),
 ]
 
 
