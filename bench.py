@@ -213,9 +213,12 @@ def main():
             def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 wino = None
-                if (depth[0] == 0 and K.WINOGRAD and x2 is None and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+                if (depth[0] == 0 and K.WINOGRAD and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+                        and (x2 is None or (x2.shape[3] == x.shape[3] and x.shape[3] % 8 == 0 and kw.get("x2_scale", 1.0) == 1.0))
                         and not {"residual", "pad", "cout_valid"} & {k for k, v in kw.items() if v is not None}):
                     wino = K.winograd_path(w.shape[2], w.shape[3])
+                    if wino == "planes" and x2 is not None:
+                        wino = None
                 e0.record()
                 depth[0] += 1
                 try:

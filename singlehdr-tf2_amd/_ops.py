@@ -117,12 +117,13 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     if not fused and pad is None and _needs_grad(x, x2, w, bias):   # fused epilogues are the inference path: never taped
         return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
                                shift=shift, residual=residual, act2=act2, algo=algo, cout_valid=cout_valid)
-    if (WINOGRAD and algo == ALGO_AUTO and x2 is None and residual is None and pad is None and cout_valid is None
-            and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)):
+    if (WINOGRAD and algo == ALGO_AUTO and residual is None and pad is None and cout_valid is None
+            and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)
+            and (x2 is None or (x2_scale == 1.0 and x2.shape[3] == x.shape[3] and x.shape[3] % 8 == 0))):
         path = winograd_path(w.shape[2], w.shape[3])
         if path == "fused":
-            return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, scale, shift, act2)
-        if path == "planes":
+            return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, scale, shift, act2, x2=x2)
+        if path == "planes" and x2 is None:
             return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
     lib = _lib.load()
     x = _chk(_d(x), "x")
@@ -832,18 +833,25 @@ def winograd_filter_packed(w):
     return u
 
 
-def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):
+def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE, x2=None):
     """3x3 / stride 1 / SAME convolution through the ONE-kernel Winograd F(2x2,3x3) (csrc/winograd_fused.hip);
-    `u` from winograd_filter_packed()"""
+    `u` from winograd_filter_packed().  `x2`: second source of a channel concatenation [x, x2] (same channel count)."""
     lib = _lib.load()
     x, u = _chk(_d(x), "x"), _chk(_d(u), "u")
     n, h, w, c = x.shape
+    c2 = 0
+    if x2 is not None:
+        x2 = _chk(_d(x2), "x2")
+        if tuple(x2.shape) != tuple(x.shape):
+            raise ValueError("conv2d_winograd_fused: x2 %s must have the shape of x %s" % (tuple(x2.shape), tuple(x.shape)))
+        c2 = c
     cout = u.shape[2]
-    if u.shape[0] != 16 or u.shape[1] != c or c % 8 or cout % 64:
+    if u.shape[0] != 16 or u.shape[1] != c + c2 or c % 8 or cout % 64:
         raise ValueError("conv2d_winograd_fused: need u [16, Cin, Cout] with Cin %% 8 == 0 and Cout %% 64 == 0")
     y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
-    _lib.check(lib.shdr_conv2d_winograd_fused_f32(_ptr(x), _ptr(u), _ptr(_d(bias)), _ptr(_d(scale)), _ptr(_d(shift)), _ptr(y),
-                                                  n, h, w, c, cout, act1, act2, _stream()), "shdr_conv2d_winograd_fused_f32")
+    _lib.check(lib.shdr_conv2d_winograd_fused2_f32(_ptr(x), _ptr(x2), _ptr(u), _ptr(_d(bias)), _ptr(_d(scale)), _ptr(_d(shift)),
+                                                   _ptr(y), n, h, w, c, c2, cout, act1, act2, _stream()),
+               "shdr_conv2d_winograd_fused2_f32")
     return y
 
 

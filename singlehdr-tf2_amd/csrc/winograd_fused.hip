@@ -42,13 +42,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __attribute__((aligned(16))) float g_wf_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct WinoFusedArgs {
-  const float* x;      // [N,H,W,Cin]
+  const float* x;      // [N,H,W,C1]
+  const float* x2;     // [N,H,W,C1] second source of a channel concatenation (or null); the channels of x come first
   const float* u;      // packed U (winograd_filter_packed_kernel)
   const float* bias;
   const float* scale;
   const float* shift;
   float* y;            // [N,H,W,Cout]
-  int N, H, W, Cin, Cout;
+  int N, H, W, Cin, Cout;   // Cin = all input channels (both sources)
+  int C1;                   // channels per source (= Cin, or Cin / 2 with x2)
   int tiles_x, tiles_y, nblk_m, nblk_n;
   int act1, act2;
 };
@@ -111,14 +113,19 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     const int py = rem / RP2, px = rem - py * RP2 - ((py >> 1) & 1);
     const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
     raw_ok[j] = quad < 2 && px >= 0 && px < PW && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-    raw_off[j] = raw_ok[j] ? ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.Cin + 4u * quad : 0u;
+    raw_off[j] = raw_ok[j] ? ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.C1 + 4u * quad : 0u;
   }
   // B operands: this lane's 16 filter values of a chunk = four float4 at up[(c*4 + j)*256], j = 2*x2 + s, .xyzw = nt 0..3
   const float* ub = a.u + (size_t)(pn * 8 + wave) * nch * 1024;     // wave-uniform: SGPR base, the lane offset stays 32-bit
+  // chunk c of the concatenated channel axis: both sources have C1 channels, so the pixel offsets are shared (wave-uniform
+  // pointer select)
+  const int nch1 = a.C1 >> 3;
   auto dma_raw = [&](int c, int buf) {
+    const float* src = c < nch1 ? a.x : a.x2;
+    const unsigned cc = (unsigned)(c < nch1 ? c : c - nch1);
 #pragma unroll
     for (int j = 0; j < RJ; ++j) {
-      const float* p = raw_ok[j] ? a.x + (size_t)(raw_off[j] + 8u * (unsigned)c) : zero;
+      const float* p = raw_ok[j] ? src + (size_t)(raw_off[j] + 8u * cc) : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(raw + buf * G::RAW_FLOATS + (wave + 8 * j) * 256), 16, 0, 0);
     }
   };
@@ -328,10 +335,14 @@ int launch_fused(WinoFusedArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
-                                              const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
-                                              int act1, int act2, void* stream) {
+extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float* u, const float* bias,
+                                               const float* scale, const float* shift, float* y, int N, int H, int W, int C1,
+                                               int C2, int Cout, int act1, int act2, void* stream) {
   SHDR_REQUIRE(x && u && y, SHDR_E_NULL, "winograd_fused: null x/u/y");
+  SHDR_REQUIRE((x2 == nullptr) == (C2 == 0), SHDR_E_NULL, "winograd_fused: x2 and C2 come together");
+  SHDR_REQUIRE(C2 == 0 || (C2 == C1 && C1 % 8 == 0 && shdr::aligned16(x2)), SHDR_E_SHAPE,
+               "winograd_fused: the two sources of a concatenation need the same channel count, a multiple of 8, 16-byte aligned");
+  const int Cin = C1 + C2;
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "winograd_fused: scale and shift come together");
   SHDR_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, SHDR_E_SHAPE, "winograd_fused: non-positive dimension");
   SHDR_REQUIRE(Cin % 8 == 0 && Cout % 64 == 0, SHDR_E_SHAPE, "winograd_fused: need Cin %% 8 == 0 and Cout %% 64 == 0");
@@ -339,12 +350,18 @@ extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, co
   SHDR_REQUIRE((long)N * H * W * Cin < (1L << 32) && 16L * Cin * Cout < (1L << 32), SHDR_E_SHAPE,
                "winograd_fused: tensor with more than 2^32 elements");
   WinoFusedArgs a{};
-  a.x = x; a.u = u; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.x = x; a.x2 = x2 ? x2 : x; a.u = u; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.C1 = C1; a.Cout = Cout;
   a.act1 = act1; a.act2 = act2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // The 16 x 16 tile (one block per CU, half the filter bytes per MFMA) was measured equal on wide layers and 5..10 % slower on
   // narrow ones (the kernel is not bound by the filter stream): it stays selectable for experiments only.
   const char* force = getenv("SHDR_WINOGRAD_TILE");        // "16": the tall tile
   return (force && force[0] == '1') ? launch_fused<2>(a, st) : launch_fused<1>(a, st);
+}
+
+extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
+                                              const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
+                                              int act1, int act2, void* stream) {
+  return shdr_conv2d_winograd_fused2_f32(x, nullptr, u, bias, scale, shift, y, N, H, W, Cin, 0, Cout, act1, act2, stream);
 }

@@ -323,6 +323,28 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
         K.winograd_filter_packed(dev(np.ascontiguousarray(wt[..., :48])))
 
 
+@pytest.mark.parametrize("shape", [(2, 13, 21, 32, 64), (1, 16, 32, 64, 128), (1, 9, 9, 8, 64), (1, 32, 16, 128, 64)])
+def test_conv2d_winograd_fused_two_sources(shdr, shape):
+    """the fused Winograd kernel on a channel concatenation [x, x2] (skip connections of the U-Net decoders): against the
+    oracle on the concatenated tensor, against the single-source kernel on a materialised concatenation (same chunk order:
+    bit-identical), and as the AUTO dispatch of conv2d(x, w, x2=...)"""
+    n, h, w, c, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x, x2 = f32(rng.normal(size=(n, h, w, c))), f32(rng.normal(size=(n, h, w, c)))
+    wt = f32(rng.normal(size=(3, 3, 2 * c, cout)) / np.sqrt(18 * c))
+    b = f32(rng.normal(size=cout))
+    u = K.winograd_filter_packed(dev(wt))
+    xc = np.concatenate([x, x2], -1)
+    y = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_LRELU, x2=dev(x2))
+    assert rel_err(host(y), oracle_conv(xc, wt, b, act1=2)) <= TOL
+    assert torch.equal(y, K.conv2d_winograd_fused(dev(xc), u, dev(b), act1=K.ACT_LRELU))
+    if 2 * c >= 32:
+        assert torch.equal(K.conv2d(dev(x), dev(wt), dev(b), x2=dev(x2), act1=K.ACT_LRELU), y)
+    with pytest.raises(ValueError, match="shape of x"):
+        K.conv2d_winograd_fused(dev(x), u, x2=dev(x2[..., :c // 2]))
+
+
 def test_conv2d_winograd_fused_tall_tile(shdr, monkeypatch):
     """the 16 x 16-pixel block tile of the fused kernel (experiment switch SHDR_WINOGRAD_TILE=16: one block per CU, 128
     accumulator registers, two raw DMA instructions per wave and chunk) against the oracle and the default 8 x 16 tile"""
