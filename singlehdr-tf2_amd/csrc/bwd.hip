@@ -73,20 +73,22 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
     }
     s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
   };
-  // two quads per trip: with the grid capped at 512 blocks one float4 pair per thread keeps only 4 MB in flight
+  // four quads per trip: the grid is capped (one atomic per block and channel on the same C addresses), so the bytes in
+  // flight have to come from the loop
   const long step = (long)gridDim.x * 256;
   long e = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; e + step < nquads; e += 2 * step) {
-    const float4 g0 = *reinterpret_cast<const float4*>(dy + 4 * e), g1 = *reinterpret_cast<const float4*>(dy + 4 * (e + step));
-    float4 y0 = g0, y1 = g1;
-    if (act != SHDR_ACT_NONE) {
-      y0 = *reinterpret_cast<const float4*>(y + 4 * e);
-      y1 = *reinterpret_cast<const float4*>(y + 4 * (e + step));
+  for (; e + 3 * step < nquads; e += 4 * step) {
+    float4 g[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g[u] = *reinterpret_cast<const float4*>(dy + 4 * (e + u * step));
+      yv[u] = g[u];
+      if (act != SHDR_ACT_NONE) yv[u] = *reinterpret_cast<const float4*>(y + 4 * (e + u * step));
     }
-    one(e, g0, y0);
-    one(e + step, g1, y1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(e + u * step, g[u], yv[u]);
   }
-  if (e < nquads) {
+  for (; e < nquads; e += step) {
     const float4 g0 = *reinterpret_cast<const float4*>(dy + 4 * e);
     float4 y0 = g0;
     if (act != SHDR_ACT_NONE) y0 = *reinterpret_cast<const float4*>(y + 4 * e);
@@ -810,7 +812,8 @@ extern "C" int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz,
   // <= 512 blocks: every block ends with one atomic per channel on the SAME C addresses (2048 blocks measured slower than
   // the unfused pair)
   int grid = shdr::stream_grid(nquads);
-  if (grid > 512) grid = 512;
+  const int cap = nquads >= (1L << 24) ? 512 : (nquads >= (1L << 23) ? 384 : 256);     // measured per tensor size
+  if (grid > cap) grid = cap;
   hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), 0, S(stream), dy, y, dz, db, nquads, Q, act);
   return shdr::check_launch("act_bwd_bias");
 }
