@@ -1090,7 +1090,14 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
     // short-K layers (1x1 expansions 64 -> 256, 128 -> 512 of the ResNet blocks) are bound by their output stream: the 128 x 64
     // tile keeps three blocks per CU in flight instead of two (0.32 -> 0.27 ms with the fused residual, 0.19 -> 0.16 without)
     if (a.Cout % 128 == 0 && a.K > 128) return launch_mfma<128, 128, 2, 2>(a, st);
-    const bool rega = a.prec == 0 && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && getenv("SHDR_NO_REGA") == nullptr;
+    // In the reduced-precision AUTO modes the exact-fp32 register-A kernel still takes the single-source layers with 4 / <= 16
+    // channels per tap and 16 (64) couts: it is faster there than the fp16-operand LDS-DMA kernel (16 x 512^2: 7x7 4->16 0.38
+    // vs 0.89 ms, 3x3 16->16 0.28 vs 0.38, 7x7 16->16 1.22 vs 1.37) and errs on the accurate side; 16+16 and 32-cout layers
+    // stay on the fp16 kernel (0.53 vs 0.57, 0.24 vs 0.30 ms).
+    const bool auto_reduced = d->algo == SHDR_ALGO_AUTO_F16 || d->algo == SHDR_ALGO_AUTO_BF16;
+    const bool rega_prec = a.prec == 0 || (auto_reduced && a.C2 == 0 && (a.Cout == 16 || a.Cout == 64));
+    const bool rega = rega_prec && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && getenv("SHDR_NO_REGA") == nullptr;
+    if (rega) a.prec = 0;
     if (rega && a.Cout == 64) return launch_rega<4, 4, 4, 3>(a, st);
     if (a.Cout % 64 == 0) return launch_mfma<128, 64, 4, 1>(a, st);
     if (rega) return a.Cout == 32 ? dispatch_rega<2>(a, st) : dispatch_rega<1>(a, st);
