@@ -292,10 +292,12 @@ int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* 
 
 /* The same kernel on a channel concatenation [x, x2] (the skip connections of the U-Net decoders:
  * dequantization_net.py:50-58, hallucination_net.py:115-144 -- tf.concat + Conv2D): both sources [N,H,W,C1], C2 == C1 (or
- * x2 == NULL, C2 == 0); u packs the filter over all C1 + C2 input channels, x's channels first. */
+ * x2 == NULL, C2 == 0); u packs the filter over all C1 + C2 input channels, x's channels first.
+ * y_pool (or NULL): [N,H/2,W/2,Cout] = MaxPool2D(2)(y) written by the same epilogue (H, W even) -- the conv + max_pool
+ * pairs of the VGG-shaped encoders (hallucination_net.py:43-75, vgg16.py:72-83), which need both tensors. */
 int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float* u, const float* bias,
-                                    const float* scale, const float* shift, float* y, int N, int H, int W, int C1,
-                                    int C2, int Cout, int act1, int act2, void* stream);
+                                    const float* scale, const float* shift, float* y, float* y_pool, int N, int H, int W,
+                                    int C1, int C2, int Cout, int act1, int act2, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

@@ -43,7 +43,7 @@ SIGNATURES = {
     "shdr_jpeg_round_trip_f32": (c_int, [c_ptr] * 6 + [c_int, c_int, c_int, c_ptr]),
     "shdr_flip_rot90_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_ptr]),
     "shdr_conv2d_winograd_fused_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
-    "shdr_conv2d_winograd_fused2_f32": (c_int, [c_ptr] * 7 + [c_int] * 8 + [c_ptr]),
+    "shdr_conv2d_winograd_fused2_f32": (c_int, [c_ptr] * 8 + [c_int] * 8 + [c_ptr]),
     "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),

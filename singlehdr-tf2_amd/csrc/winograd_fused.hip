@@ -49,6 +49,7 @@ struct WinoFusedArgs {
   const float* scale;
   const float* shift;
   float* y;            // [N,H,W,Cout]
+  float* yp;           // [N,H/2,W/2,Cout] 2x2 max-pool of y (or null): a Winograd tile is exactly one pooling window
   int N, H, W, Cin, Cout;   // Cin = all input channels (both sources)
   int C1;                   // channels per source (= Cin, or Cin / 2 with x2)
   int tiles_x, tiles_y, nblk_m, nblk_n;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
         s[0][j] = m0 + m1 + m2;
         s[1][j] = m1 - m2 - m3;
       }
+      float pm = -3.0e38f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int oh = oh0 + 2 * tyy + i;
@@ -307,8 +309,12 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
           if (a.scale) v = v * sc + sh;
           v = shdr::act_apply(v, a.act2);
           a.y[((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + cg] = v;
+          pm = fmaxf(pm, v);
         }
       }
+      // fused MaxPool2D(2): H and W are even, so a tile inside the image has all four outputs
+      if (a.yp && oh0 + 2 * tyy < a.H && ow0 + 2 * txx < a.W)
+        a.yp[((size_t)(img * (a.H >> 1) + (oh0 >> 1) + tyy) * (a.W >> 1) + (ow0 >> 1) + txx) * a.Cout + cg] = pm;
     }
     __syncthreads();
   }
@@ -336,8 +342,9 @@ int launch_fused(WinoFusedArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float* u, const float* bias,
-                                               const float* scale, const float* shift, float* y, int N, int H, int W, int C1,
-                                               int C2, int Cout, int act1, int act2, void* stream) {
+                                               const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
+                                               int W, int C1, int C2, int Cout, int act1, int act2, void* stream) {
+  SHDR_REQUIRE(y_pool == nullptr || (H % 2 == 0 && W % 2 == 0), SHDR_E_SHAPE, "winograd_fused: the fused 2x2 max-pool needs even H, W");
   SHDR_REQUIRE(x && u && y, SHDR_E_NULL, "winograd_fused: null x/u/y");
   SHDR_REQUIRE((x2 == nullptr) == (C2 == 0), SHDR_E_NULL, "winograd_fused: x2 and C2 come together");
   SHDR_REQUIRE(C2 == 0 || (C2 == C1 && C1 % 8 == 0 && shdr::aligned16(x2)), SHDR_E_SHAPE,
@@ -350,7 +357,7 @@ extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, 
   SHDR_REQUIRE((long)N * H * W * Cin < (1L << 32) && 16L * Cin * Cout < (1L << 32), SHDR_E_SHAPE,
                "winograd_fused: tensor with more than 2^32 elements");
   WinoFusedArgs a{};
-  a.x = x; a.x2 = x2 ? x2 : x; a.u = u; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
+  a.x = x; a.x2 = x2 ? x2 : x; a.u = u; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = y_pool;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.C1 = C1; a.Cout = Cout;
   a.act1 = act1; a.act2 = act2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -363,5 +370,5 @@ extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, 
 extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* bias, const float* scale,
                                               const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
                                               int act1, int act2, void* stream) {
-  return shdr_conv2d_winograd_fused2_f32(x, nullptr, u, bias, scale, shift, y, N, H, W, Cin, 0, Cout, act1, act2, stream);
+  return shdr_conv2d_winograd_fused2_f32(x, nullptr, u, bias, scale, shift, y, nullptr, N, H, W, Cin, 0, Cout, act1, act2, stream);
 }

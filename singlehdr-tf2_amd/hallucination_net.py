@@ -29,8 +29,8 @@ class down1(Layer):
             x = self.conv1.call_padded(x, cin_pad=x.shape[-1], act1=K.ACT_RELU)
         else:
             x = self.conv1(x, act1=K.ACT_RELU)
-        skip_layer = self.conv2(x, act1=K.ACT_RELU)
-        return K.maxpool2(skip_layer), skip_layer
+        skip_layer, pooled = K.conv2d_maxpool2(x, self.conv2.kernel, self.conv2.bias, act1=K.ACT_RELU)
+        return pooled, skip_layer
 
 
 class down2(Layer):
@@ -45,8 +45,8 @@ class down2(Layer):
     def call(self, x):
         x = self.conv1(x, act1=K.ACT_RELU)
         x = self.conv2(x, act1=K.ACT_RELU)
-        skip_layer = self.conv3(x, act1=K.ACT_RELU)
-        return K.maxpool2(skip_layer), skip_layer
+        skip_layer, pooled = K.conv2d_maxpool2(x, self.conv3.kernel, self.conv3.bias, act1=K.ACT_RELU)
+        return pooled, skip_layer
 
 
 class up(Layer):

@@ -345,6 +345,28 @@ def test_conv2d_winograd_fused_two_sources(shdr, shape):
         K.conv2d_winograd_fused(dev(x), u, x2=dev(x2[..., :c // 2]))
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32, 32, 64), (1, 10, 22, 64, 128), (1, 2, 2, 8, 64), (1, 34, 18, 40, 64)])
+def test_conv2d_winograd_fused_maxpool(shdr, shape):
+    """MaxPool2D(2) written by the epilogue of the fused Winograd kernel (a Winograd tile is one pooling window): the conv
+    output is unchanged bit for bit, the pooled tensor equals maxpool2 of it exactly; ragged block tiles, even H and W"""
+    n, h, w, c, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, c)))
+    wt = f32(rng.normal(size=(3, 3, c, cout)) / np.sqrt(9 * c))
+    b = f32(rng.normal(size=cout))
+    u = K.winograd_filter_packed(dev(wt))
+    y, yp = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU, pool=True)
+    y0 = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU)
+    assert torch.equal(y, y0) and tuple(yp.shape) == (n, h // 2, w // 2, cout)
+    assert torch.equal(yp, K.maxpool2(y0))
+    if c >= 32:
+        y2, yp2 = K.conv2d_maxpool2(dev(x), dev(wt), dev(b), act1=K.ACT_RELU)       # the dispatching wrapper
+        assert torch.equal(y2, y) and torch.equal(yp2, yp)
+    with pytest.raises(ValueError, match="even"):
+        K.conv2d_winograd_fused(dev(x[:, :h - 1]), u, pool=True)
+
+
 def test_conv2d_winograd_fused_tall_tile(shdr, monkeypatch):
     """the 16 x 16-pixel block tile of the fused kernel (experiment switch SHDR_WINOGRAD_TILE=16: one block per CU, 128
     accumulator registers, two raw DMA instructions per wave and chunk) against the oracle and the default 8 x 16 tile"""
