@@ -294,7 +294,8 @@ int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* 
  * dequantization_net.py:50-58, hallucination_net.py:115-144 -- tf.concat + Conv2D): both sources [N,H,W,C1], C2 == C1 (or
  * x2 == NULL, C2 == 0); u packs the filter over all C1 + C2 input channels, x's channels first.
  * y_pool (or NULL): [N,H/2,W/2,Cout] = MaxPool2D(2)(y) written by the same epilogue (H, W even) -- the conv + max_pool
- * pairs of the VGG-shaped encoders (hallucination_net.py:43-75, vgg16.py:72-83), which need both tensors. */
+ * pairs of the VGG-shaped encoders (hallucination_net.py:43-75 needs both tensors; vgg16.py:72-83 only the pooled one:
+ * y may then be NULL and is not stored). */
 int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float* u, const float* bias,
                                     const float* scale, const float* shift, float* y, float* y_pool, int N, int H, int W,
                                     int C1, int C2, int Cout, int act1, int act2, void* stream);

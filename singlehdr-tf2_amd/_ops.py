@@ -836,7 +836,8 @@ def winograd_filter_packed(w):
 def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE, x2=None, pool=False):
     """3x3 / stride 1 / SAME convolution through the ONE-kernel Winograd F(2x2,3x3) (csrc/winograd_fused.hip);
     `u` from winograd_filter_packed().  `x2`: second source of a channel concatenation [x, x2] (same channel count).
-    `pool=True` returns (y, MaxPool2D(2)(y)), the pooled tensor written by the same epilogue (H, W even)."""
+    `pool=True` returns (y, MaxPool2D(2)(y)), the pooled tensor written by the same epilogue (H, W even); `pool="only"`
+    returns the pooled tensor alone and y is never stored."""
     lib = _lib.load()
     x, u = _chk(_d(x), "x"), _chk(_d(u), "u")
     n, h, w, c = x.shape
@@ -849,7 +850,7 @@ def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None
     cout = u.shape[2]
     if u.shape[0] != 16 or u.shape[1] != c + c2 or c % 8 or cout % 64:
         raise ValueError("conv2d_winograd_fused: need u [16, Cin, Cout] with Cin %% 8 == 0 and Cout %% 64 == 0")
-    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    y = None if pool == "only" else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
     yp = None
     if pool:
         if h % 2 or w % 2:
@@ -858,17 +859,17 @@ def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None
     _lib.check(lib.shdr_conv2d_winograd_fused2_f32(_ptr(x), _ptr(x2), _ptr(u), _ptr(_d(bias)), _ptr(_d(scale)), _ptr(_d(shift)),
                                                    _ptr(y), _ptr(yp), n, h, w, c, c2, cout, act1, act2, _stream()),
                "shdr_conv2d_winograd_fused2_f32")
-    return (y, yp) if pool else y
+    return yp if pool == "only" else ((y, yp) if pool else y)
 
 
-def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE):
+def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
     """(y, MaxPool2D(2)(y)) with y = act1(conv3x3(x, w) + bias): ONE launch on the fused Winograd kernel where it applies
-    (inference, even H and W), the conv + maxpool2 pair otherwise."""
+    (inference, even H and W), the conv + maxpool2 pair otherwise.  keep_y=False returns the pooled tensor only."""
     if (WINOGRAD and PRECISION == "fp32" and not _needs_grad(x, w, bias) and tuple(w.shape[:2]) == (3, 3)
             and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and winograd_path(w.shape[2], w.shape[3]) == "fused"):
-        return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, pool=True)
+        return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, pool=True if keep_y else "only")
     y = conv2d(x, w, bias, act1=act1)
-    return y, maxpool2(y)
+    return (y, maxpool2(y)) if keep_y else maxpool2(y)
 
 
 def conv2d_winograd(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
           v = shdr::act_apply(v + bv, a.act1);
           if (a.scale) v = v * sc + sh;
           v = shdr::act_apply(v, a.act2);
-          a.y[((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + cg] = v;
+          if (a.y) a.y[((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + cg] = v;
           pm = fmaxf(pm, v);
         }
       }
@@ -345,7 +345,7 @@ extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, 
                                                const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
                                                int W, int C1, int C2, int Cout, int act1, int act2, void* stream) {
   SHDR_REQUIRE(y_pool == nullptr || (H % 2 == 0 && W % 2 == 0), SHDR_E_SHAPE, "winograd_fused: the fused 2x2 max-pool needs even H, W");
-  SHDR_REQUIRE(x && u && y, SHDR_E_NULL, "winograd_fused: null x/u/y");
+  SHDR_REQUIRE(x && u && (y || y_pool), SHDR_E_NULL, "winograd_fused: null x/u or neither y nor y_pool");
   SHDR_REQUIRE((x2 == nullptr) == (C2 == 0), SHDR_E_NULL, "winograd_fused: x2 and C2 come together");
   SHDR_REQUIRE(C2 == 0 || (C2 == C1 && C1 % 8 == 0 && shdr::aligned16(x2)), SHDR_E_SHAPE,
                "winograd_fused: the two sources of a concatenation need the same channel count, a multiple of 8, 16-byte aligned");

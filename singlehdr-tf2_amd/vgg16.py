@@ -45,12 +45,15 @@ class Vgg16(Layer):
         w, b = self.params[name]
         return K.conv2d(x, w, b, act1=K.ACT_RELU)   # vgg16.py:33-35
 
+    def _conv_pool(self, name, x):
+        w, b = self.params[name]
+        return K.conv2d_maxpool2(x, w, b, act1=K.ACT_RELU, keep_y=False)
+
     def call(self, rgb, training="training"):
         x = K.vgg_preprocess(rgb, 4)                 # vgg16.py:101-109 (+ zero 4th channel)
-        x = self._conv("conv1_2", self._conv("conv1_1", x))
-        pool1 = K.maxpool2(x)
-        x = self._conv("conv2_2", self._conv("conv2_1", pool1))
-        pool2 = K.maxpool2(x)
-        x = self._conv("conv3_3", self._conv("conv3_2", self._conv("conv3_1", pool2)))
-        pool3 = K.maxpool2(x)
+        # only the pooled tensors leave the net: without a tape (the target branch of the perceptual loss) the last conv of a
+        # block writes MaxPool2D(2)(relu(conv)) straight from the fused Winograd epilogue and never stores the conv output
+        pool1 = self._conv_pool("conv1_2", self._conv("conv1_1", x))
+        pool2 = self._conv_pool("conv2_2", self._conv("conv2_1", pool1))
+        pool3 = self._conv_pool("conv3_3", self._conv("conv3_2", self._conv("conv3_1", pool2)))
         return pool1, pool2, pool3

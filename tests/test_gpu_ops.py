@@ -360,6 +360,7 @@ def test_conv2d_winograd_fused_maxpool(shdr, shape):
     y0 = K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU)
     assert torch.equal(y, y0) and tuple(yp.shape) == (n, h // 2, w // 2, cout)
     assert torch.equal(yp, K.maxpool2(y0))
+    assert torch.equal(K.conv2d_winograd_fused(dev(x), u, dev(b), act1=K.ACT_RELU, pool="only"), yp)    # y never stored
     if c >= 32:
         y2, yp2 = K.conv2d_maxpool2(dev(x), dev(wt), dev(b), act1=K.ACT_RELU)       # the dispatching wrapper
         assert torch.equal(y2, y) and torch.equal(yp2, yp)
