@@ -180,6 +180,33 @@ def main():
                               "ms_per_step": round(ddt * 1e3, 3), "images_per_s": round(x8.shape[0] / ddt, 2),
                               "tflops_algorithmic": round(37.83 * (args.size / 512.0) ** 2 * x8.shape[0] / ddt / 1e3, 2)}
 
+    # ---- the HBM-bound kernels of the path against the HBM roofline (soft histogram standalone at B = 32,
+    #      and the fused front end of the Linearization-Net as it runs inside the step) ----------
+    if rank == 0 and not args.no_roofline:
+        try:
+            def hbm_rate(fn, nbytes, reps=10):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                return {"ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved": round(nbytes / ms / 1e6, 1),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4)}
+            npix = args.batch * args.size * args.size
+            result["hbm_kernels"] = {
+                "soft_hist_kernel B=32 (standalone, not a reference value of B)":
+                    hbm_rate(lambda: K.soft_hist(ldr, 32), npix * (12 + 384)),
+                "lin_frontend_rows_kernel (image + sobel + B=4/8/16 histograms -> 96 ch)":
+                    hbm_rate(lambda: K.lin_frontend(ldr, 96), npix * (12 + 384)),
+            }
+        except Exception as exc:      # an auxiliary leg must never cost the headline line
+            result["hbm_kernels_error"] = repr(exc)[:300]
+
     # ---- the same inference with the Refinement-Net appended ("report with and without") ----------
     if not args.no_refinement:
         torch.manual_seed(4321)

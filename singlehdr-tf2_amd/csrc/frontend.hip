@@ -60,6 +60,54 @@ __global__ __launch_bounds__(256) void soft_hist_quad_kernel(const float* __rest
   }
 }
 
+// Same output, HBM-bound form: the grid stride is a multiple of the quads per pixel, so a thread keeps ONE output quad
+// position (4 channels = 4 (bin, colour) pairs) for all its pixels; the four bin centres -- the IEEE divides of soft_bin --
+// and the channel indices are computed once per thread instead of once per element, and the 64-bit e / Q per store is gone.
+// The per-element arithmetic is soft_bin's, bit for bit.
+__global__ __launch_bounds__(256) void soft_hist_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long npix,
+                                                             int C, int B, float thr) {
+#pragma clang fp contract(off)
+  const int Q = (B * C) >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int q = (int)(t % Q);
+  const long dp = ((long)gridDim.x * 256) / Q;              // exact: the launcher makes the stride a multiple of Q
+  const float two_b = (float)(2 * B), nb = (float)B;
+  int cc[4];
+  float centre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ch = 4 * q + k;
+    const int bin = ch / C;
+    cc[k] = ch - bin * C;
+    centre[k] = __fdiv_rn((float)(2 * (bin + 1) - 1), two_b);
+  }
+  auto one = [&](long p, const float* xv) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = fabsf(__fsub_rn(xv[k], centre[k]));
+      v[k] = d < thr ? __fsub_rn(1.0f, __fmul_rn(d, nb)) : 0.0f;
+    }
+    *reinterpret_cast<float4*>(y + (p * Q + q) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  long p = t / Q;
+  for (; p + 3 * dp < npix; p += 4 * dp) {                  // four pixels in flight
+    float xv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xv[u][k] = x[(p + u * dp) * C + cc[k]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(p + u * dp, xv[u]);
+  }
+  for (; p < npix; p += dp) {
+    float xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = x[p * C + cc[k]];
+    one(p, xv);
+  }
+}
+
 __device__ __forceinline__ int reflect(int i, int n) {  // REFLECT pad by 1
   return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
 }
@@ -184,9 +232,20 @@ extern "C" int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const float thr = (float)(1.0 / (double)B);  // Python double 1./max_bin cast to fp32
   if (((B * C) & 3) == 0 && shdr::aligned16(y)) {
-    const long total = (long)npix * ((B * C) >> 2);
-    hipLaunchKernelGGL(soft_hist_quad_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, x, y,
-                       (long)npix, C, B, thr);
+    const int Q = (B * C) >> 2;
+    const long total = (long)npix * Q;
+    // smallest grid unit whose 256-thread blocks make the stride a multiple of Q: Q / gcd(Q, 256) blocks
+    int g = Q, h = 256;
+    while (h) { const int r = g % h; g = h; h = r; }
+    const long unit = Q / g;
+    if (unit <= 64 && getenv("SHDR_FRONTEND_QUADS") == nullptr) {
+      long grid = shdr::stream_grid(total);
+      grid = (grid + unit - 1) / unit * unit;
+      hipLaunchKernelGGL(soft_hist_rows_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, y, (long)npix, C, B, thr);
+    } else {
+      hipLaunchKernelGGL(soft_hist_quad_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, x, y,
+                         (long)npix, C, B, thr);
+    }
   } else {
     const long total = (long)npix * B * C;
     hipLaunchKernelGGL(soft_hist_scalar_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, st, x,

@@ -163,6 +163,17 @@ def test_soft_hist_bit_exact(shdr, B):
     np.testing.assert_array_equal(y > 0, ref > 0)    # "which bins fire" index predicate
 
 
+@pytest.mark.parametrize("B", [32, 12])
+def test_soft_hist_bit_exact_grid_stride(shdr, B):
+    """enough pixels that every thread of soft_hist_rows_kernel walks its 4-pixel-unrolled grid-stride loop and its tail
+    (B = 12: 9 quads per pixel, the stride unit is 9 blocks)"""
+    rng = np.random.default_rng(100 + B)
+    x = f32(quantised_image(rng, (5, 163, 160, 3)))
+    ref = ops.histogram_layer(x, B)
+    y = host(shdr._ops.soft_hist(dev(x), B))
+    np.testing.assert_array_equal(y.view(np.uint32), ref.view(np.uint32))
+
+
 def test_soft_hist_known_answer_lin2(shdr):
     x = f32(np.array([0.63, 0.65, 0.32, 0.84, 0.15]).reshape(1, 1, 5, 1))
     y = host(shdr._ops.soft_hist(dev(x), 5))[0, 0]
