@@ -126,13 +126,22 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i] + b[i];
 }
 
-#define SHDR_DECODE_QUAD(e, Q, Wd, Hd, q, w, h, n) \
-  const int q = (int)((e) % (Q));                  \
-  long _t = (e) / (Q);                              \
-  const int w = (int)(_t % (Wd));                   \
-  _t /= (Wd);                                       \
-  const int h = (int)(_t % (Hd));                   \
-  const long n = _t / (Hd);
+// (e < 2^32 for every tensor below 64 GB: three 32-bit divisions -- about 25 instructions each -- instead of three emulated
+//  64-bit ones, which cost more than the whole rest of these HBM-bound kernels; wider indices keep the 64-bit path)
+#define SHDR_DECODE_QUAD(e, Q, Wd, Hd, q, w, h, n)                     \
+  int q, w, h;                                                          \
+  long n;                                                               \
+  if ((unsigned long)(e) <= 0xffffffffUL) {                             \
+    unsigned _t = (unsigned)(e);                                        \
+    q = (int)(_t % (unsigned)(Q)); _t /= (unsigned)(Q);                 \
+    w = (int)(_t % (unsigned)(Wd)); _t /= (unsigned)(Wd);               \
+    h = (int)(_t % (unsigned)(Hd)); n = (long)(_t / (unsigned)(Hd));    \
+  } else {                                                              \
+    long _t = (e);                                                      \
+    q = (int)(_t % (Q)); _t /= (Q);                                     \
+    w = (int)(_t % (Wd)); _t /= (Wd);                                   \
+    h = (int)(_t % (Hd)); n = _t / (Hd);                                \
+  }
 
 // ---- pooling / resize backward (gather form: one thread per INPUT quad) ------------------------
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,

@@ -11,13 +11,22 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
 
 // decode e -> (n, oh, ow, q) for an output of [N, Ho, Wo, 4*Q]
-#define SHDR_DECODE_QUAD(e, Q, Wo, Ho, q, ow, oh, n) \
-  const int q = (int)((e) % (Q));                   \
-  long _t = (e) / (Q);                               \
-  const int ow = (int)(_t % (Wo));                   \
-  _t /= (Wo);                                        \
-  const int oh = (int)(_t % (Ho));                   \
-  const long n = _t / (Ho);
+// (e < 2^32 for every tensor below 64 GB: three 32-bit divisions -- about 25 instructions each -- instead of three emulated
+//  64-bit ones, which cost more than the whole rest of these HBM-bound kernels; wider indices keep the 64-bit path)
+#define SHDR_DECODE_QUAD(e, Q, Wd, Hd, q, w, h, n)                     \
+  int q, w, h;                                                          \
+  long n;                                                               \
+  if ((unsigned long)(e) <= 0xffffffffUL) {                             \
+    unsigned _t = (unsigned)(e);                                        \
+    q = (int)(_t % (unsigned)(Q)); _t /= (unsigned)(Q);                 \
+    w = (int)(_t % (unsigned)(Wd)); _t /= (unsigned)(Wd);               \
+    h = (int)(_t % (unsigned)(Hd)); n = (long)(_t / (unsigned)(Hd));    \
+  } else {                                                              \
+    long _t = (e);                                                      \
+    q = (int)(_t % (Q)); _t /= (Q);                                     \
+    w = (int)(_t % (Wd)); _t /= (Wd);                                   \
+    h = (int)(_t % (Hd)); n = _t / (Hd);                                \
+  }
 
 // AveragePooling2D(2,2) VALID (dequantization_net.py:10)
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -80,27 +89,50 @@ __global__ __launch_bounds__(256) void resize2x_kernel(const float* __restrict__
   const int Q = C >> 2;
   const long total = (long)N * H * W * Q;
   const long orow = (long)2 * W * C;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  auto vl = [](float4 t, float4 u, float ly) {
+    return make_float4(t.x + (u.x - t.x) * ly, t.y + (u.y - t.y) * ly, t.z + (u.z - t.z) * ly, t.w + (u.w - t.w) * ly);
+  };
+  // the 9 loads of one input quad
+  auto load9 = [&](long e, float4 (&v)[3][3], float*& o) {
     SHDR_DECODE_QUAD(e, Q, W, H, q, w, h, n)
     const int hm = max(h - 1, 0), hp = min(h + 1, H - 1), wm = max(w - 1, 0), wp = min(w + 1, W - 1);
     const float* b = x + (n * H * (long)W) * C + 4 * q;
     const int rows[3] = {hm, h, hp};
-    float4 lo[3], hi[3];   // horizontally interpolated: lo = output column 2w, hi = output column 2w+1
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const float* rp = b + (long)rows[r] * W * C;
-      const float4 l = ld4(rp + (long)wm * C), c = ld4(rp + (long)w * C), rr = ld4(rp + (long)wp * C);
+      v[r][0] = ld4(rp + (long)wm * C); v[r][1] = ld4(rp + (long)w * C); v[r][2] = ld4(rp + (long)wp * C);
+    }
+    o = y + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * C + 4 * q;
+  };
+  auto emit = [&](const float4 (&v)[3][3], float* o) {
+    float4 lo[3], hi[3];   // horizontally interpolated: lo = output column 2w, hi = output column 2w+1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 l = v[r][0], c = v[r][1], rr = v[r][2];
       lo[r] = make_float4(l.x + (c.x - l.x) * 0.75f, l.y + (c.y - l.y) * 0.75f, l.z + (c.z - l.z) * 0.75f, l.w + (c.w - l.w) * 0.75f);
       hi[r] = make_float4(c.x + (rr.x - c.x) * 0.25f, c.y + (rr.y - c.y) * 0.25f, c.z + (rr.z - c.z) * 0.25f, c.w + (rr.w - c.w) * 0.25f);
     }
-    auto vl = [](float4 t, float4 u, float ly) {
-      return make_float4(t.x + (u.x - t.x) * ly, t.y + (u.y - t.y) * ly, t.z + (u.z - t.z) * ly, t.w + (u.w - t.w) * ly);
-    };
-    float* o = y + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * C + 4 * q;
     st4(o, vl(lo[0], lo[1], 0.75f));
     st4(o + C, vl(hi[0], hi[1], 0.75f));
     st4(o + orow, vl(lo[1], lo[2], 0.25f));
     st4(o + orow + C, vl(hi[1], hi[2], 0.25f));
+  };
+  const long step = (long)gridDim.x * 256;
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; e + step < total; e += 2 * step) {       // two input quads (18 loads) in flight
+    float4 va[3][3], vb[3][3];
+    float *oa, *ob;
+    load9(e, va, oa);
+    load9(e + step, vb, ob);
+    emit(va, oa);
+    emit(vb, ob);
+  }
+  if (e < total) {
+    float4 va[3][3];
+    float* oa;
+    load9(e, va, oa);
+    emit(va, oa);
   }
 }
 
