@@ -265,6 +265,16 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   float* Ms = smem;
   constexpr int NTILES = 32 * R;
   const int co = tid & 31, tg = tid >> 5;    // thread = (cout of the half, tile group); tiles tg + 16*k
+  // per-channel epilogue constants of both halves, requested before the first LDS pass so that their L2 latency sits under
+  // the accumulator writes instead of in front of each half's output transform
+  float bvh[2], sch[2], shh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cg = n0 + 32 * h + co;
+    bvh[h] = a.bias ? a.bias[cg] : 0.0f;
+    sch[h] = a.scale ? a.scale[cg] : 1.0f;
+    shh[h] = a.scale ? a.shift[cg] : 0.0f;
+  }
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -280,9 +290,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
           }
     __syncthreads();
     const int cg = n0 + 32 * h + co;
-    const float bv = a.bias ? a.bias[cg] : 0.0f;
-    const float sc = a.scale ? a.scale[cg] : 1.0f;
-    const float sh = a.scale ? a.shift[cg] : 0.0f;
+    const float bv = h == 0 ? bvh[0] : bvh[1], sc = h == 0 ? sch[0] : sch[1], sh = h == 0 ? shh[0] : shh[1];
 #pragma unroll 1
     for (int k = 0; k < 2 * R; ++k) {
       const int tile = tg + 16 * k, tyy = tile >> 3, txx = tile & 7;

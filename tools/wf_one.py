@@ -8,10 +8,12 @@ hw, cin, cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 x = torch.randn(N, hw, hw, cin, device="cuda"); w = torch.randn(3, 3, cin, cout, device="cuda") * 0.02
 u = K.winograd_filter_packed(w)
-for _ in range(3): K.conv2d_winograd_fused(x, u)
+b = torch.randn(cout, device="cuda"); sc = torch.rand(cout, device="cuda") + 0.5; sh = torch.randn(cout, device="cuda")
+kw = dict(bias=b, act1=K.ACT_RELU, scale=sc, shift=sh, act2=K.ACT_RELU) if os.environ.get("WF_EPI") else {}
+for _ in range(3): K.conv2d_winograd_fused(x, u, **kw)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
-for _ in range(10): K.conv2d_winograd_fused(x, u)
+for _ in range(10): K.conv2d_winograd_fused(x, u, **kw)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 gf = 2.0 * N * hw * hw * cin * cout * 9 / 1e9
