@@ -892,12 +892,13 @@ int launch_mfma_dma_impl(ConvArgs& a, hipStream_t st) {
   a.nblk_m = a.N * a.tiles_y * a.tiles_x;
   a.nblk_n = a.Cout / BN;
   constexpr int lds = conv_dma_lds_bytes<BM, BN>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_dma_kernel<BM, BN, WM, WN, FAST, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d: grid of %ld blocks", nblk);
@@ -913,12 +914,13 @@ int launch_mfma_impl(ConvArgs& a, hipStream_t st) {
   a.nblk_m = a.N * a.tiles_y * a.tiles_x;
   a.nblk_n = a.Cout / BN;
   constexpr int lds = conv_lds_bytes<BM, BN>();
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BM, BN, WM, WN, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d: grid of %ld blocks", nblk);
@@ -950,7 +952,9 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
   a.tiles_y = (a.Ho + TH - 1) / TH;
   const long ntiles = (long)a.N * a.tiles_y * a.tiles_x;
   const int lds = a.ntaps * CT * NT * 16 * 4;
-  static int attr_lds = 0;
+  const int dev_slot = shdr::device_slot();
+  static int attr_lds_dev[shdr::kMaxDevices] = {};
+  int& attr_lds = attr_lds_dev[dev_slot];
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT, KK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -959,7 +963,8 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
   }
   // persistent grid = the blocks that are actually co-resident (VGPR- or LDS-limited): a grid that is not a multiple of the
   // residency runs its last blocks alone at low occupancy (measured: 768 blocks with 2 resident per CU cost +20 %)
-  static int occ_lds = -1, occ = 0;
+  static int occ_lds_dev[shdr::kMaxDevices] = {}, occ_dev[shdr::kMaxDevices] = {};
+  int &occ_lds = occ_lds_dev[dev_slot], &occ = occ_dev[dev_slot];     // (LDS bytes are never 0 here: 0 = not queried yet)
   if (lds != occ_lds) {
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_rega_kernel<MT, NT, CT, KK>), 256, lds);

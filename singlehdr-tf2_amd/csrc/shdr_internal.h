@@ -29,6 +29,15 @@ inline int check_launch(const char* what) {
   return SHDR_OK;
 }
 
+// Launch-time state that HIP keeps per device (hipFuncSetAttribute, occupancy) is cached per device, not per process: a host
+// that drives several GPUs from one process (the reference's tf.distribute.MirroredStrategy layout) gets it right as well.
+constexpr int kMaxDevices = 16;
+inline int device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  return d & (kMaxDevices - 1);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define SHDR_REQUIRE(cond, code, ...) \

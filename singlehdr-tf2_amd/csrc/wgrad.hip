@@ -455,12 +455,13 @@ int launch_wgrad_prec(WgradArgs& a, hipStream_t st) {
   a.tiles_m = (a.Cx + BMc - 1) / BMc;
   a.tiles_n = (a.Cout + BNc - 1) / BNc;
   constexpr int lds = 2 * PK * (BMc + BNc) * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<BMc, BNc, WM, WN, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    attr_done[dev_slot] = true;
   }
   // enough pixel slices to fill the chip ~4x, but at least 2048 pixels per slice to bound the atomics
   const long tiles = (long)a.KH * a.KW * a.tiles_m * a.tiles_n;

@@ -260,12 +260,13 @@ extern "C" int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, f
   const long nslices = (a.units + slice - 1) / slice;
   SHDR_REQUIRE(nslices <= 65535, SHDR_E_SHAPE, "wgrad_winograd: too many unit slices");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_winograd_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WW<2>::LDS_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    attr_done[dev_slot] = true;
   }
   hipLaunchKernelGGL(wgrad_winograd_kernel<2>, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), WW<2>::LDS_BYTES, st, a);
   if (int rc = shdr::check_launch("wgrad_winograd_kernel")) return rc;

@@ -336,12 +336,13 @@ int launch_fused(WinoFusedArgs& a, hipStream_t st) {
   a.nblk_n = a.Cout / 64;
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "winograd_fused: grid of %ld blocks", nblk);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_fused_kernel<R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WF<R>::LDS_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    attr_done[dev_slot] = true;
   }
   hipLaunchKernelGGL(winograd_fused_kernel<R>, dim3((unsigned)nblk), dim3(512), WF<R>::LDS_BYTES, st, a);
   return shdr::check_launch("winograd_fused_kernel");
