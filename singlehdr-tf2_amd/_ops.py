@@ -579,6 +579,7 @@ def bn_stats(x, moving_mean=None, moving_var=None, momentum=0.99):
     ws = _bn_ws(c, x.device)
     _lib.check(lib.shdr_bn_stats_f32(_ptr(x), _ptr(ws), _ptr(mean), _ptr(var), _ptr(_d(moving_mean)), _ptr(_d(moving_var)),
                                      x.numel() // c, c, float(momentum), _stream()), "shdr_bn_stats_f32")
+    _mutated(moving_mean, moving_var)
     return mean, var
 
 
@@ -733,6 +734,17 @@ def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0
         _chk(_d(t), nm)
     _lib.check(lib.shdr_adam_f32(_ptr(_d(p)), _ptr(_d(g)), _ptr(m), _ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
                                  float(eps), float(grad_scale), _stream()), "shdr_adam_f32")
+    _mutated(p, m, v)
+
+
+def _mutated(*tensors):
+    """The C ABI writes through raw pointers, so torch does not see an in-place update: bump the version counter (shared by a
+    buffer and all its views) of every tensor a kernel has modified -- the per-version caches of the layers (zero-padded /
+    x2-scaled filters, folded BatchNorm constants) key on it, and a stale cache would serve pre-update weights to an inference
+    call that follows a training step."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 def lin_frontend_bwd(img, dF):

@@ -1,4 +1,5 @@
 """GPU tests of the joint training step (joint_training.py:137-194) against the float64 reference."""
+import importlib
 import math
 
 import numpy as np
@@ -157,3 +158,28 @@ def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     s_deq((ldr, jpeg, mask))
     assert not torch.equal(b["deq"].trainable_variables[0].detach(), before)
     assert s_deq.optimizer.lr == 1e-4 and s_deq.params.num_params == 1999779
+
+
+def test_inference_caches_follow_in_place_updates(shdr):
+    """Adam and the BatchNorm moving statistics are updated by kernels through raw pointers; the per-version caches of the
+    layers (padded / x2-scaled filters, folded BN constants) must notice: an inference call after a training step uses the
+    updated values."""
+    K = shdr._ops
+    L = importlib.import_module("singlehdr-tf2_amd._layers")
+    torch.manual_seed(3)
+    conv = L.Conv2D(3, 3, (1, 1))
+    bn = L.BatchNormalization(16)
+    x4 = torch.rand(1, 8, 8, 4, device="cuda")
+    params = shdr.pipeline.FlatParams([conv])
+    with torch.no_grad():
+        y0 = conv.call_padded(x4, cin_pad=4, cout_pad=16).clone()             # fills the padded-filter cache
+    s0 = bn.folded()[0].clone()
+    params.grad.fill_(1.0)
+    shdr.pipeline.KerasAdam(params, 0.1).step()                                # kernel writes params.flat in place
+    with torch.no_grad():
+        y1 = conv.call_padded(x4, cin_pad=4, cout_pad=16)
+    assert float((y1 - y0).abs().max()) > 1e-3                                 # not the stale cached filter
+    ref = K.conv2d(x4, torch.nn.functional.pad(conv.kernel.detach(), (0, 13, 0, 1)).contiguous(), conv.bias.detach(), cout_valid=3)
+    assert torch.equal(y1, ref)
+    K.bn_stats(torch.randn(2, 8, 8, 16, device="cuda") * 3 + 1, bn.moving_mean, bn.moving_variance)   # moving stats updated in place
+    assert float((bn.folded()[0] - s0).abs().max()) > 1e-4
