@@ -143,6 +143,10 @@ class KerasAdam:
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         K.adam_step(self.p.flat, self.p.grad, self.p.m, self.p.v, lr_t, self.b1, self.b2, self.eps, grad_scale)
+        # the variables alias the flat buffer through `.data` and keep their OWN version counters: tell torch (and with it the
+        # per-version caches of the layers) that every one of them has just been rewritten
+        for v in self.p.variables:
+            torch.autograd.graph.increment_version(v)
 
 
 class JointTrainStep:
