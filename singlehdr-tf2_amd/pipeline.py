@@ -69,10 +69,16 @@ class GraphedInference:
     """`Inference` captured once into a HIP graph (hipGraph via torch.cuda.CUDAGraph) and replayed: the
     ~100 kernel launches of one forward become ONE graph launch, which removes the launch gaps that
     dominate small-batch latency (the reference's tool runs one image at a time,
-    test_real_refinement.py:119-155).  Shapes are static: one graph per input shape, kept in a cache."""
+    test_real_refinement.py:119-155).  Shapes are static: one graph per input shape, kept in a cache.  The graph holds the
+    derived constants of capture time (packed Winograd filters, padded filters, folded BatchNorm): call `reset()` after the
+    weights change (checkpoint restore, training step)."""
 
     def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD):
         self._eager = Inference(deq, lin, hal, ref, threshold)
+        self._graphs = {}
+
+    def reset(self):
+        """drop the captured graphs (weights changed)"""
         self._graphs = {}
 
     def __call__(self, ldr):
