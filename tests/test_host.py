@@ -2,6 +2,7 @@
 symbol include/shdr.h declares, host-side validation fails loudly, the drop-in
 modules expose the reference's call surface.  No kernel is launched here."""
 import ctypes
+import importlib
 import os
 import re
 import sys
@@ -145,3 +146,24 @@ def test_product_never_imports_the_oracle():
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_documented_ctypes_mirror_matches_the_header():
+    """INTEGRATION.md shows the ctypes mirror of shdr_conv2d_desc a maintainer would write; it must list the fields of the
+    struct in include/shdr.h (same names, same order) -- a short mirror makes the library read past the caller's struct."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "shdr.h")).read()
+    body = hdr[hdr.index("typedef struct shdr_conv2d_desc {"):hdr.index("} shdr_conv2d_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for typ, names in re.findall(r"(int32_t|int64_t|float)\s+([^;]+);", body):
+        c_fields += [(n.strip(), typ) for n in names.split(",")]
+    lib = importlib.import_module("singlehdr-tf2_amd._lib")
+    ctype = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
+    assert [(n, ctype[t]) for n, t in c_fields] == list(lib.ConvDesc._fields_)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    snippet = doc[doc.index("class ConvDesc(ctypes.Structure):"):doc.index("lib.shdr_conv2d_fwd_f32.restype")]
+    ns = {"ctypes": ctypes}
+    exec(snippet, ns)
+    assert [(n, t) for n, t in ns["ConvDesc"]._fields_] == list(lib.ConvDesc._fields_)
