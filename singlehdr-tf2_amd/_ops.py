@@ -432,7 +432,9 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
     x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
     if x2 is not None:
         _chk(_d(x2), "x2")
-    if (WINOGRAD and PRECISION == "fp32" and (kh, kw) == (3, 3) and stride == 1 and c1 % 32 == 0 and c2 % 32 == 0
+    # (in the reduced-precision modes too for <= 64 channels per source: the exact Winograd-domain kernel is faster there than the
+    #  fp16-operand kernel -- 16 x 512^2 x 64 -> 64: 1.77 vs 2.98 ms -- and errs on the accurate side)
+    if (WINOGRAD and (PRECISION == "fp32" or max(c1, c2) <= 64) and (kh, kw) == (3, 3) and stride == 1 and c1 % 32 == 0 and c2 % 32 == 0
             and cout % 64 == 0 and cin == c1 + c2 and cout == dz.shape[3] and tuple(dz.shape[:3]) == tuple(x.shape[:3])):
         # Winograd-domain weight gradient (csrc/wgrad_winograd.hip): 2.25x fewer MFMAs than the direct form
         n, h, w, _ = x.shape
