@@ -122,7 +122,7 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
             and (x2 is None or (x2_scale == 1.0 and x2.shape[3] == x.shape[3] and x.shape[3] % 8 == 0))):
         path = winograd_path(w.shape[2], w.shape[3])
         if path == "fused":
-            return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, scale, shift, act2, x2=x2)
+            return conv2d_winograd_fused(x, _packed_filter(w), bias, act1, scale, shift, act2, x2=x2)
         if path == "planes" and x2 is None:
             return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
     lib = _lib.load()
@@ -876,12 +876,26 @@ def conv2d_winograd_fused(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None
     return yp if pool == "only" else ((y, yp) if pool else y)
 
 
+def _packed_filter(w):
+    """winograd_filter_packed(w), kept ON the filter tensor per version for persistent variables (requires_grad leaves: the
+    layers' kernels): an inference step then packs nothing (33 launches per step).  Temporaries (transposed dgrad filters)
+    are packed per call.  Every kernel that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
+    if not (w.requires_grad and w.is_leaf):
+        return winograd_filter_packed(w)
+    cached = getattr(w, "_shdr_packed", None)
+    if cached is not None and cached[0] == w._version:
+        return cached[1]
+    u = winograd_filter_packed(w)
+    w._shdr_packed = (w._version, u)
+    return u
+
+
 def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
     """(y, MaxPool2D(2)(y)) with y = act1(conv3x3(x, w) + bias): ONE launch on the fused Winograd kernel where it applies
     (inference, even H and W), the conv + maxpool2 pair otherwise.  keep_y=False returns the pooled tensor only."""
     if (WINOGRAD and PRECISION == "fp32" and not _needs_grad(x, w, bias) and tuple(w.shape[:2]) == (3, 3)
             and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and winograd_path(w.shape[2], w.shape[3]) == "fused"):
-        return conv2d_winograd_fused(x, winograd_filter_packed(w), bias, act1, pool=True if keep_y else "only")
+        return conv2d_winograd_fused(x, _packed_filter(w), bias, act1, pool=True if keep_y else "only")
     y = conv2d(x, w, bias, act1=act1)
     return (y, maxpool2(y)) if keep_y else maxpool2(y)
 

@@ -181,5 +181,18 @@ def test_inference_caches_follow_in_place_updates(shdr):
     assert float((y1 - y0).abs().max()) > 1e-3                                 # not the stale cached filter
     ref = K.conv2d(x4, torch.nn.functional.pad(conv.kernel.detach(), (0, 13, 0, 1)).contiguous(), conv.bias.detach(), cout_valid=3)
     assert torch.equal(y1, ref)
+    # the packed Winograd filter kept on a persistent kernel follows the update as well
+    wide = L.Conv2D(32, 64, (3, 3))
+    p2 = shdr.pipeline.FlatParams([wide])
+    x32 = torch.rand(1, 16, 16, 32, device="cuda")
+    with torch.no_grad():
+        z0 = wide(x32).clone()
+        assert getattr(wide.kernel, "_shdr_packed", None) is not None and torch.equal(wide(x32), z0)    # second call: cache hit
+    p2.grad.fill_(-1.0)
+    shdr.pipeline.KerasAdam(p2, 0.05).step()
+    with torch.no_grad():
+        z1 = wide(x32)
+        fresh = K.conv2d_winograd_fused(x32, K.winograd_filter_packed(wide.kernel.detach()), wide.bias.detach())
+    assert torch.equal(z1, fresh) and float((z1 - z0).abs().max()) > 1e-2
     K.bn_stats(torch.randn(2, 8, 8, 16, device="cuda") * 3 + 1, bn.moving_mean, bn.moving_variance)   # moving stats updated in place
     assert float((bn.folded()[0] - s0).abs().max()) > 1e-4
