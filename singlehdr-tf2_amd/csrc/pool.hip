@@ -145,8 +145,21 @@ __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, f
   const int c0 = blockIdx.x * 64 + 4 * q;
   const long n = blockIdx.y;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c0 < C)
-    for (int p = g; p < HW; p += 16) s = add4(s, ld4(x + (n * HW + p) * (long)C + c0));
+  if (c0 < C) {
+    // four independent loads in flight per thread: the sequential form ran at the latency of 16 dependent loads (0.12 ms for
+    // the 33 MB of the Linearization-Net's 16 x 256 x 2048 tensor)
+    const float* xb = x + n * HW * (long)C + c0;
+    float4 s1 = s, s2 = s, s3 = s;
+    int p = g;
+    for (; p + 48 < HW; p += 64) {
+      s = add4(s, ld4(xb + (long)p * C));
+      s1 = add4(s1, ld4(xb + (long)(p + 16) * C));
+      s2 = add4(s2, ld4(xb + (long)(p + 32) * C));
+      s3 = add4(s3, ld4(xb + (long)(p + 48) * C));
+    }
+    for (; p < HW; p += 16) s = add4(s, ld4(xb + (long)p * C));
+    s = add4(add4(s, s1), add4(s2, s3));
+  }
   part[g][q] = s;
   __syncthreads();
   if (g == 0 && c0 < C) {
