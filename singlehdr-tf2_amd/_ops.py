@@ -880,7 +880,7 @@ def _packed_filter(w):
     """winograd_filter_packed(w), kept ON the filter tensor per version for persistent variables (requires_grad leaves: the
     layers' kernels): an inference step then packs nothing (33 launches per step).  Temporaries (transposed dgrad filters)
     are packed per call.  Every kernel that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
-    if not (w.requires_grad and w.is_leaf):
+    if not ((w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)):     # _shdr_const: frozen weights (VGG16)
         return winograd_filter_packed(w)
     cached = getattr(w, "_shdr_packed", None)
     if cached is not None and cached[0] == w._version:

@@ -40,6 +40,7 @@ class Vgg16(Layer):
             if cin == 3:   # zero-pad Cin 3 -> 4: the first conv runs on the MFMA tile
                 w = torch.cat([w, torch.zeros(3, 3, 1, cout)], dim=2)
             self.params[name] = (w.contiguous().to(device), b.contiguous().to(device))
+            self.params[name][0]._shdr_const = True     # frozen: the packed Winograd form is kept on the tensor (_ops._packed_filter)
 
     def _conv(self, name, x):
         w, b = self.params[name]
