@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--finetune-steps", type=int, default=2, help="timed fine-tuning steps per precision (0 = skip that leg)")
     ap.add_argument("--finetune-batch", type=int, default=4)       # finetune_real_dataset.py:25
     ap.add_argument("--finetune-size", type=int, default=1024)
+    ap.add_argument("--finetune-prec", default="fp32,fp16", help="comma list of the fine-tuning precisions to time")
     return ap.parse_args()
 
 
@@ -471,7 +472,7 @@ def main():
                            "%dx%d tiles per GPU; fp16 = fp16 operands of v_mfma_f32_16x16x32_f16 in every conv "
                            "fwd/dgrad/wgrad, fp32 tensors in HBM, fp32 accumulate" % (b, sz, sz),
                "n_gpus": world, "scaling": "weak", "steps": args.finetune_steps}
-        for prec in ("fp32", "fp16"):
+        for prec in [p for p in args.finetune_prec.split(",") if p]:
             torch.manual_seed(777)
             nets4 = [pkg.dequantization_net.model(), pkg.linearization_net.model(), pkg.hallucination_net.model(),
                      pkg.refinement_net.model()]

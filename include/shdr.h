@@ -184,6 +184,11 @@ int shdr_pack3_fwd_f32(const float* s0, const float* s1, const float* s2, const 
 int shdr_pad_channels_f32(const float* x, float* y, int64_t npix, int Cin, int Cout, void* stream);
 /* log(1+10x)/log(11) (joint_training.py:166,173). */
 int shdr_logc_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+/* y = act(x * scale[c] + shift[c] + residual) on [npix, C] (scale / shift / residual may be null): the inference
+ * BatchNormalization + residual join + relu of linearization_net.py:13-47,55-82 and hallucination_net.py:88-89,164-165 as a
+ * stand-alone op, for a `net(x, training=False)` call recorded on a gradient tape (frozen BatchNorm statistics). */
+int shdr_affine_act_f32(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                        int64_t npix, int C, int act, void* stream);
 
 /* ---- backward / training (GradientTape.gradient + Adam.apply_gradients:
  *      joint_training.py:185-186, train.py:175-176,195-196,242-243,

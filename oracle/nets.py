@@ -317,7 +317,11 @@ def joint_losses(params, vgg_params, batch, invcrf_gt, table, thr=0.12):
     loss_deq = ops.l2_loss_with_mask(c_pred, ldr) * mask
     pred_invcrf = lin_forward(params["lin"], ldr, table, training=True)
     b_pred = ops.apply_rf(ldr, pred_invcrf)
-    crf_loss = ((pred_invcrf - invcrf_gt) ** 2).mean(axis=1, keepdims=True).reshape(-1, 1, 1, 1)
+    # joint_training.py:158-160: crf_loss keeps its [b,1] shape, so `10 * l2loss_lin [b,1,1,1] + crf_loss [b,1]` BROADCASTS to
+    # [b,1,b,1] (element [i,0,j,0] = 10 * l2_i + crf_j) and so does everything added to it.  tape.gradient differentiates the
+    # sum of all b*b elements: b * sum_i (per-sample terms)_i + (sum_i mask_i) * sum_j crf_j -- every per-sample term is
+    # weighted by the batch size and a masked sample still receives crf gradient.  Restated as the reference computes it.
+    crf_loss = ((pred_invcrf - invcrf_gt) ** 2).mean(axis=1, keepdims=True)
     loss_lin = (10.0 * ops.l2_loss_with_mask(b_pred, clipped) + crf_loss) * mask
     hal = hal_forward(params["hal"], clipped, training=True)
     a_pred = clipped + alpha * ops.reverse_channels(hal)

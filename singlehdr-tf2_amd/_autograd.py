@@ -154,6 +154,38 @@ def batch_norm_train(x, gamma, beta, moving_mean, moving_var, eps, momentum, rel
     return BatchNormTrainFn.apply(x, gamma, beta, moving_mean, moving_var, eps, momentum, relu)
 
 
+class BatchNormFrozenFn(torch.autograd.Function):
+    """y = act(gamma * (x - moving_mean) / sqrt(moving_var + eps) + beta [+ residual]): BatchNormalization called with
+    training=False while a tape is recording (tf.keras semantics: the moving statistics are constants, gamma and beta still
+    receive gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, residual, act):
+        x = _c(x.detach())
+        scale = (gamma.detach() * torch.rsqrt(var + eps)).contiguous()       # C-sized vectors: plumbing
+        shift = (beta.detach() - mean * scale).contiguous()
+        y = K.affine_act(x, scale, shift, None if residual is None else _c(residual.detach()), act)
+        ctx.save_for_backward(x, y if act != K.ACT_NONE else None, gamma, mean, var, scale)
+        ctx.meta = (eps, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, var, scale = ctx.saved_tensors
+        eps, act = ctx.meta
+        d = K.act_bwd(_c(dy), y, act) if act != K.ACT_NONE else _c(dy)
+        dx = K.affine_act(d, scale) if ctx.needs_input_grad[0] else None
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # sum(d * (x - mean) * rstd), sum(d): the reductions of the training-mode backward on the moving statistics
+            _, dgamma, dbeta = K.bn_bwd(d, x, None, mean.detach(), var.detach(), gamma, eps)
+        return dx, dgamma, dbeta, None, None, None, (d if ctx.needs_input_grad[6] else None), None
+
+
+def batch_norm_frozen(x, gamma, beta, moving_mean, moving_var, eps, residual=None, act=K.ACT_NONE):
+    return BatchNormFrozenFn.apply(x, gamma, beta, moving_mean, moving_var, eps, residual, act)
+
+
 # ---------------------------------------------------------------------------
 # pooling / resize / elementwise
 # ---------------------------------------------------------------------------
@@ -232,6 +264,34 @@ def vgg_preprocess(x, out_channels=3):
 
 def increase(rf):
     return IncreaseFn.apply(rf)
+
+
+class AffineActFn(torch.autograd.Function):
+    """y = act(x * scale[c] + shift[c] + residual); scale / shift are constants (folded moving statistics)"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, act):
+        y = K.affine_act(x.detach(), _det(scale), _det(shift), _det(residual), act)
+        ctx.save_for_backward(y if act != K.ACT_NONE else None, scale)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        d = K.act_bwd(_c(dy), y, ctx.act) if ctx.act != K.ACT_NONE else _c(dy)
+        dx = K.affine_act(d, _det(scale)) if (scale is not None and ctx.needs_input_grad[0]) else d
+        return dx, None, None, (d if ctx.needs_input_grad[3] else None), None
+
+
+def _det(t):
+    return None if t is None else t.detach()
+
+
+def affine_act(x, scale, shift, residual, act):
+    if (scale is not None and scale.requires_grad) or (shift is not None and shift.requires_grad):
+        raise NotImplementedError("affine_act: scale / shift are folded constants, not trainable inputs")
+    return AffineActFn.apply(x, scale, shift, residual, act)
 
 
 class AddFn(torch.autograd.Function):

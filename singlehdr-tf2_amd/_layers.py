@@ -177,6 +177,13 @@ class BatchNormalization(Layer):
                                            BN_EPS, BN_MOMENTUM, relu)
 
 
+    def frozen_apply(self, x, residual=None, relu=False):
+        """Inference mode on a gradient tape (`net(x, training=False)` while fine-tuning with frozen statistics): normalise with
+        the moving statistics [+ residual] [+ relu]; gamma / beta and x (and the residual) receive gradients."""
+        return K.AUTOGRAD.batch_norm_frozen(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, BN_EPS,
+                                            residual, K.ACT_RELU if relu else K.ACT_NONE)
+
+
 class Dense(Layer):
     """tf.keras.layers.Dense(units)."""
 

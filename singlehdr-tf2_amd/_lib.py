@@ -69,6 +69,7 @@ SIGNATURES = {
     "shdr_alpha_blend_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     "shdr_pack3_fwd_f32": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_ptr]),
     "shdr_logc_fwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_affine_act_f32": (c_int, [c_ptr] * 5 + [c_i64, c_int, c_int, c_ptr]),
     "shdr_pad_channels_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_act_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "shdr_clip_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_ptr]),

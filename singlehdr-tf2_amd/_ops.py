@@ -114,9 +114,17 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     if algo == ALGO_AUTO:
         algo = _AUTO_ALGO[PRECISION]
     fused = scale is not None or shift is not None or residual is not None or act2 != ACT_NONE
-    if not fused and pad is None and _needs_grad(x, x2, w, bias):   # fused epilogues are the inference path: never taped
-        return AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, scale=scale,
-                               shift=shift, residual=residual, act2=act2, algo=algo, cout_valid=cout_valid)
+    if _needs_grad(x, x2, w, bias, scale, shift, residual):
+        if pad is not None or out_hw is not None or out is not None or w_batch_stride:
+            raise NotImplementedError("conv2d: pad / out_hw / out / w_batch_stride are raw-kernel options (input-gradient and "
+                                      "Winograd plumbing) and cannot be recorded on a gradient tape")
+        y = AUTOGRAD.conv2d(x, w, bias, stride=stride, x2=x2, x2_scale=x2_scale, act1=act1, algo=algo, cout_valid=cout_valid)
+        if not fused:
+            return y
+        # A fused inference epilogue (folded BatchNorm, residual join, second activation) under a tape -- e.g.
+        # `lin(x, training=False)` while fine-tuning with frozen BatchNorm statistics: recorded as conv + affine/join/activation,
+        # two tape entries, instead of silently returning a tensor that is cut off from the graph.
+        return AUTOGRAD.affine_act(y, scale, shift, residual, act2)
     if (WINOGRAD and algo == ALGO_AUTO and residual is None and pad is None and cout_valid is None
             and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)
             and (x2 is None or (x2_scale == 1.0 and x2.shape[3] == x.shape[3] and x.shape[3] % 8 == 0))):
@@ -525,6 +533,24 @@ def add(a, b):
         raise ValueError("add: shape mismatch")
     y = torch.empty_like(a)
     _lib.check(lib.shdr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "shdr_add_f32")
+    return y
+
+
+def affine_act(x, scale=None, shift=None, residual=None, act=ACT_NONE):
+    """act(x * scale[c] + shift[c] + residual) on NHWC"""
+    if _needs_grad(x, scale, shift, residual):
+        return AUTOGRAD.affine_act(x, scale, shift, residual, act)
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    c = x.shape[-1]
+    for t, nm in ((scale, "scale"), (shift, "shift")):
+        if t is not None and _chk(_d(t), nm).numel() != c:
+            raise ValueError("affine_act: %s must have %d elements" % (nm, c))
+    if residual is not None and _chk(_d(residual), "residual").shape != x.shape:
+        raise ValueError("affine_act: residual shape %s != %s" % (tuple(residual.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    _lib.check(lib.shdr_affine_act_f32(_ptr(x), _ptr(_d(scale)), _ptr(_d(shift)), _ptr(_d(residual)), _ptr(y), x.numel() // c, c,
+                                       act, _stream()), "shdr_affine_act_f32")
     return y
 
 

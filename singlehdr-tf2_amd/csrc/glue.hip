@@ -91,7 +91,65 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
   }
 }
 
+// y = act(x * scale[c] + shift[c] + residual): the folded-BatchNorm / residual / second-activation epilogue of the inference
+// convs as a stand-alone op -- used when such a layer runs under a gradient tape (frozen BatchNorm statistics), where the
+// conv, the affine map and the join have to be separate tape entries.  C % 4 == 0, float4 per thread.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res,
+                                                         float* __restrict__ y, long nquads, int cq, int act) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    const int c = 4 * (int)(q % cq);
+    float4 v = *reinterpret_cast<const float4*>(x + 4 * q);
+    if (scale) {
+      const float4 s4 = *reinterpret_cast<const float4*>(scale + c);
+      v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+    }
+    if (shift) {
+      const float4 t4 = *reinterpret_cast<const float4*>(shift + c);
+      v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+    }
+    if (res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(res + 4 * q);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    v.x = shdr::act_apply(v.x, act); v.y = shdr::act_apply(v.y, act);
+    v.z = shdr::act_apply(v.z, act); v.w = shdr::act_apply(v.w, act);
+    *reinterpret_cast<float4*>(y + 4 * q) = v;
+  }
+}
+
+// any channel count (the 3-channel heads): one element per thread
+__global__ __launch_bounds__(256) void affine_act_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ res,
+                                                                float* __restrict__ y, long n, int C, int act) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    float v = x[e];
+    if (scale) v *= scale[c];
+    if (shift) v += shift[c];
+    if (res) v += res[e];
+    y[e] = shdr::act_apply(v, act);
+  }
+}
+
 }  // namespace
+
+extern "C" int shdr_affine_act_f32(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                                   int64_t npix, int C, int act, void* stream) {
+  SHDR_REQUIRE(x && y, SHDR_E_NULL, "affine_act: null pointer");
+  SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "affine_act: need npix > 0 and C > 0");
+  const bool vec = C % 4 == 0 && shdr::aligned16(x) && shdr::aligned16(y) && (!scale || shdr::aligned16(scale)) &&
+                   (!shift || shdr::aligned16(shift)) && (!residual || shdr::aligned16(residual));
+  if (!vec) {
+    hipLaunchKernelGGL(affine_act_scalar_kernel, dim3(shdr::stream_grid((long)npix * C)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, scale, shift, residual, y, (long)npix * C, C, act);
+    return shdr::check_launch("affine_act");
+  }
+  const long nquads = (long)npix * (C / 4);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(shdr::stream_grid(nquads)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     scale, shift, residual, y, nquads, C / 4, act);
+  return shdr::check_launch("affine_act");
+}
 
 extern "C" int shdr_pad_channels_f32(const float* x, float* y, int64_t npix, int Cin, int Cout, void* stream) {
   SHDR_REQUIRE(x && y, SHDR_E_NULL, "pad_channels: null pointer");

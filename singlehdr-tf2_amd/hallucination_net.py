@@ -10,10 +10,10 @@ import torch
 
 try:
     from . import _ops as K
-    from ._layers import Layer, Conv2D, BatchNormalization, is_training
+    from ._layers import Layer, Conv2D, BatchNormalization, is_training, taping
 except ImportError:
     import _ops as K
-    from _layers import Layer, Conv2D, BatchNormalization, is_training
+    from _layers import Layer, Conv2D, BatchNormalization, is_training, taping
 
 
 class down1(Layer):
@@ -62,6 +62,8 @@ class up(Layer):
         x = K.resize2x(x)
         if is_training(training):       # relu(conv) -> batch-statistics BN -> relu, separate taped ops
             return self.norm1.train_apply(self.conv1(x, act1=K.ACT_RELU), relu=True)
+        if taping(x, self.conv1.kernel, self.norm1.gamma):     # inference mode on a tape: frozen statistics, separate tape entries
+            return self.norm1.frozen_apply(self.conv1(x, act1=K.ACT_RELU), relu=True)
         scale, shift = self.norm1.folded()
         return self.conv1(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
 
@@ -116,8 +118,11 @@ class model(Layer):
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)
         enc, d5 = self.d5(x)
+        frozen = not train and taping(input_layer, self.conv1.kernel, self.norm1.gamma)
         if train:
             x = self.norm1.train_apply(self.conv1(enc), relu=True)
+        elif frozen:
+            x = self.norm1.frozen_apply(self.conv1(enc), relu=True)
         else:
             sc, sh = self.norm1.folded()
             x = self.conv1(enc, scale=sc, shift=sh, act2=K.ACT_RELU)   # conv -> BN -> relu (:163-165)
@@ -128,6 +133,8 @@ class model(Layer):
         x = self.s1(self.u1(x, training), d1)
         if train:
             x = self.norm2.train_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
+        elif frozen:
+            x = self.norm2.frozen_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
         else:
             sc, sh = self.norm2.folded()
             x = self.conv2.call_padded(x, cout_pad=16, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:183-185)

@@ -32,10 +32,12 @@ MULTIPLE = 64         # :129-133
 
 
 def read_ldr(path):
-    """8-bit image file -> uint8 RGB [H, W, 3] (cv2.imread drops alpha and converts grey to 3 channels as well)"""
-    from PIL import Image
+    """8-bit image file -> uint8 RGB [H, W, 3] (cv2.imread drops alpha and converts grey to 3 channels as well).  Like
+    cv2.imread with its default flags (test_real_refinement.py:124) the EXIF Orientation tag is APPLIED: a camera JPEG stored
+    rotated comes back upright."""
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
-        return np.array(im.convert("RGB"), dtype=np.uint8)          # a writable copy
+        return np.array(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8)          # a writable copy
 
 
 def rle_encode(rgbe):

@@ -18,10 +18,10 @@ import torch
 
 try:
     from . import _ops as K
-    from ._layers import Layer, Conv2D, BatchNormalization, Dense, is_training
+    from ._layers import Layer, Conv2D, BatchNormalization, Dense, is_training, taping
 except ImportError:
     import _ops as K
-    from _layers import Layer, Conv2D, BatchNormalization, Dense, is_training
+    from _layers import Layer, Conv2D, BatchNormalization, Dense, is_training, taping
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FRONTEND_CHANNELS = 93          # linearization_net.py:322
@@ -39,10 +39,15 @@ def _conv_bn(conv, norm, x, relu, residual=None, cin_pad=None, training=False):
             return norm.train_apply(z, relu=relu)
         y = norm.train_apply(z, relu=False)
         return K.AUTOGRAD.add_relu(residual, y) if relu else K.add(residual, y)
+    if taping(x, residual, conv.kernel, conv.bias, norm.gamma, norm.beta):
+        # inference mode while a tape records (frozen statistics): conv and the normalisation / join are separate tape entries
+        z = conv(x) if cin_pad is None else conv.call_padded(x, cin_pad=cin_pad)
+        return norm.frozen_apply(z, residual, relu)
     scale, shift = norm.folded()
-    w = conv.kernel if cin_pad is None else conv.kernel_padded(cin_pad)
-    return K.conv2d(x, w, conv.bias, stride=conv.strides, scale=scale, shift=shift, residual=residual,
-                    act2=K.ACT_RELU if relu else K.ACT_NONE)
+    kw = dict(scale=scale, shift=shift, residual=residual, act2=K.ACT_RELU if relu else K.ACT_NONE)
+    if cin_pad is None:
+        return K.conv2d(x, conv.kernel, conv.bias, stride=conv.strides, **kw)
+    return conv.call_padded(x, cin_pad=cin_pad, **kw)     # (under a tape the zero-padding of the filter is part of the tape)
 
 
 class resBlock_type1(Layer):

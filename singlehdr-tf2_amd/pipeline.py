@@ -71,9 +71,12 @@ class GraphedInference:
     dominate small-batch latency (the reference's tool runs one image at a time,
     test_real_refinement.py:119-155).  Shapes are static: one graph per input shape, kept in a cache.  The graph holds the
     derived constants of capture time (packed Winograd filters, padded filters, folded BatchNorm): call `reset()` after the
-    weights change (checkpoint restore, training step)."""
+    weights change (checkpoint restore, training step).
+    The returned tensor IS the graph's static output buffer: the next call with the same input shape overwrites it in place
+    (`.clone()` it to keep a result across calls, or pass `copy_output=True`)."""
 
-    def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD):
+    def __init__(self, deq, lin, hal, ref=None, threshold=THRESHOLD, copy_output=False):
+        self._copy_output = copy_output
         self._eager = Inference(deq, lin, hal, ref, threshold)
         self._graphs = {}
 
@@ -100,7 +103,7 @@ class GraphedInference:
         graph, static_in, static_out = entry
         static_in.copy_(ldr)
         graph.replay()
-        return static_out
+        return static_out.clone() if self._copy_output else static_out
 
 
 class FlatParams:
@@ -155,14 +158,35 @@ class KerasAdam:
             torch.autograd.graph.increment_version(v)
 
 
+def _dp_scalars(step, mask):
+    """(global batch size, global sum(loss_mask)) of a data-parallel step: the two batch-coupled scalars of the losses (the
+    factor B of the broadcast loss, the crf weight, the batch-global TV mean).  One scalar all-reduce; equal shard sizes."""
+    msum = mask.sum()
+    if step.pg is not None and step.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(msum, group=step.pg)
+    return float(mask.numel() * step.world), msum
+
+
+def _broadcast_lin_loss(l2_term, crf_loss, mask):
+    """(l2_term [b,1,1,1] + crf_loss [b,1]) * loss_mask [b,1,1,1] -> [b,1,b,1], the shapes (and therefore the broadcast) of
+    joint_training.py:158-160 and train.py:189-191; inputs are the per-sample vectors [b]"""
+    b = mask.numel()
+    return (l2_term.reshape(b, 1, 1, 1) + crf_loss.reshape(b, 1)) * mask.reshape(b, 1, 1, 1)
+
+
 class JointTrainStep:
     """The `train_step(ds, invcrf)` closure of joint_training.py:137-194.
 
-    deq, lin and hal are fed ground-truth intermediates (jpeg, ldr, clipped_hdr_t); the loss is
-    per-sample [b] and its SUM over the batch is differentiated (tape.gradient of a non-scalar).
+    deq, lin and hal are fed ground-truth intermediates (jpeg, ldr, clipped_hdr_t).  The reference keeps `crf_loss` as
+    [b,1] and adds it to the [b,1,1,1] L2 term (joint_training.py:158-160), so `loss_lin` and `total_loss` BROADCAST to
+    [b,1,b,1] (element [i,0,j,0] = per-sample terms of i + mask_i * crf_j) and tape.gradient differentiates the sum of all
+    b*b elements:   B * sum_i (loss_deq_i + 10 * mask_i * l2_i + loss_hal_i)  +  (sum_i mask_i) * sum_j crf_j,   B = batch size.
+    That objective is reproduced exactly (`objective()`), including the factor B on every gradient (it matters through
+    Adam's epsilon) and the crf gradient a masked sample still receives.
     Data parallel: weights replicated, batch sharded, ONE all_reduce(SUM) of the flat
-    gradient over RCCL; BatchNorm statistics are per replica; the batch-global TV mean is made exact by a
-    scalar all-reduce of sum(loss_mask)."""
+    gradient over RCCL; BatchNorm statistics are per replica; B and sum(loss_mask) are the GLOBAL ones (a scalar
+    all-reduce of sum(loss_mask)), which also keeps the batch-global TV mean exact."""
 
     LEARNING_RATE = 1e-5   # joint_training.py:20
     THRESHOLD = 0.12       # joint_training.py:140
@@ -195,8 +219,9 @@ class JointTrainStep:
         with torch.cuda.stream(streams[1]):   # Linearization (:156-160)
             pred_invcrf = self._lin(ldr, training=True)
             B_pred = tf_utils.apply_rf(ldr, pred_invcrf)
-            crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
-            loss_lin = (10.0 * K.diff_loss(B_pred, clipped_hdr_t, 0) + crf_loss) * mask
+            crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)                         # [b] here, [b,1] in the reference
+            l2_lin = K.diff_loss(B_pred, clipped_hdr_t, 0)
+            loss_lin = _broadcast_lin_loss(10.0 * l2_lin, crf_loss, mask)            # [b,1,b,1]
 
         with torch.cuda.stream(streams[2]):   # Hallucination (:163-182)
             alpha = K.alpha_mask(clipped_hdr_t, thr)
@@ -210,25 +235,24 @@ class JointTrainStep:
             perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
             l1loss_hal = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
             tv_loss = K.tv_loss(y_final_gamma)                                     # batch-global scalar [1]
-            tv_w = mask
-            if self.pg is not None and self.world > 1:
-                # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
-                import torch.distributed as dist
-                msum = mask.sum()
-                dist.all_reduce(msum, group=self.pg)
-                tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
+            b_glob, msum = _dp_scalars(self, mask)
+            # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
+            tv_w = mask if self.world == 1 else torch.ones_like(mask) * (msum / b_glob)
             loss_hal = (l1loss_hal + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
 
         for st in streams:
             main.wait_stream(st)
-        total_loss = loss_deq + loss_lin + loss_hal
-        return dict(total=total_loss, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal, crf_loss=crf_loss,
-                    C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)
+        b = mask.numel()
+        total_loss = (loss_deq + loss_hal).reshape(b, 1, 1, 1) + loss_lin          # [b,1,b,1] (:183)
+        # the scalar tape.gradient differentiates (class docstring), with the GLOBAL batch size and mask sum under DP
+        objective = b_glob * (loss_deq.sum() + (10.0 * l2_lin * mask).sum() + loss_hal.sum()) + msum * crf_loss.sum()
+        return dict(total=total_loss, objective=objective, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
+                    crf_loss=crf_loss, C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)
 
     def __call__(self, ds, invcrf, apply=True):
         self.params.zero_grad()
         out = self.losses(ds, invcrf)
-        out["total"].sum().backward()                     # gradient of the batch-summed loss
+        out["objective"].backward()                       # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)   # the ONE gradient collective
@@ -260,6 +284,7 @@ class TrainStep:
         self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
         self.pg, self.world = process_group, world_size
         self.last_loss = None
+        self._objective = None
 
     def forward(self, ds):
         """(per-sample loss [b], the list the reference's step returns)"""
@@ -272,8 +297,13 @@ class TrainStep:
             pred_invcrf = self.net(ldr, training=True)
             pred_lin_ldr = tf_utils.apply_rf(ldr, pred_invcrf)
             crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)
-            loss = (K.diff_loss(pred_lin_ldr, clipped_hdr_t, 0) + 0.1 * crf_loss) * loss_mask.reshape(-1)
-            return loss, [pred_lin_ldr, crf_loss.detach().mean()]
+            l2 = K.diff_loss(pred_lin_ldr, clipped_hdr_t, 0)
+            mask = loss_mask.reshape(-1)
+            # train.py:189-191: `loss [b,1,1,1] + 0.1 * crf_loss [b,1]` broadcasts to [b,1,b,1] like the joint step's loss_lin;
+            # the differentiated sum is  B * sum_i mask_i * l2_i + 0.1 * (sum_i mask_i) * sum_j crf_j  (global B, mask sum under DP)
+            b_glob, msum = _dp_scalars(self, mask)
+            self._objective = b_glob * (l2 * mask).sum() + 0.1 * msum * crf_loss.sum()
+            return _broadcast_lin_loss(l2, 0.1 * crf_loss, mask), [pred_lin_ldr, crf_loss.detach().mean()]
         hdr_t, clipped_hdr_t, loss_mask = ds         # train.py:203-244
         mask = loss_mask.reshape(-1)
         alpha = K.alpha_mask(clipped_hdr_t, self.THRESHOLD)
@@ -288,11 +318,9 @@ class TrainStep:
         loss = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
         tv_loss = K.tv_loss(y_final_gamma)
         tv_w = mask
-        if self.pg is not None and self.world > 1:   # exact sharding of the batch-global TV mean, as in JointTrainStep
-            import torch.distributed as dist
-            msum = mask.sum()
-            dist.all_reduce(msum, group=self.pg)
-            tv_w = torch.ones_like(mask) * (msum / (self.world * mask.numel()))
+        if self.world > 1:                            # exact sharding of the batch-global TV mean, as in JointTrainStep
+            b_glob, msum = _dp_scalars(self, mask)
+            tv_w = torch.ones_like(mask) * (msum / b_glob)
         hal_loss = (loss + 0.001 * perceptual_loss) * mask + 0.1 * tv_loss * tv_w
         with torch.no_grad():
             pred_rgb = tf_utils.bgr2rgb(bgr_pred.detach())
@@ -300,8 +328,10 @@ class TrainStep:
 
     def __call__(self, ds, apply=True):
         self.params.zero_grad()
+        self._objective = None
         loss, outputs = self.forward(ds)
-        loss.sum().backward()                        # tape.gradient of the per-sample loss = gradient of its sum
+        # tape.gradient of a non-scalar loss = gradient of its sum (for `lin` the sum over the broadcast [b,1,b,1] tensor)
+        (loss.sum() if self._objective is None else self._objective).backward()
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)

@@ -1,0 +1,148 @@
+"""BASELINE configs[4] ("finetune_real_dataset.py with Refinement-Net, 1024x1024 tiles, fp16 MFMA conv path") against the
+float64 ORACLE -- not against the HIP fp32 kernels (tests/test_gpu_fp16.py does that and only shows that two HIP paths agree).
+
+Stated fp16 bounds (unit round-off u = 2^-11 = 4.9e-4; operands -- and, in the native-fp16 layout, stored activations -- are
+rounded to nearest-even, accumulation is fp32):
+  * one conv layer, forward / input gradient / weight gradient:  max|err| <= 3e-3 * max|reference tensor|;
+  * the chained fine-tuning step (finetune_real_dataset.py:144-183, ~80 conv layers deep): intermediates and the loss within
+    2e-2 / 1e-2 relative of the oracle, flat 29 M-parameter gradient within cosine >= 0.95 of the float64 autograd reference
+    (whole-net gradients of these training-mode nets move by 1-3.5 % under a 1e-6 input perturbation, test_gpu_grad.py);
+  * 4 x 1024^2 (the configuration's own size; the oracle would take hours): size-independent properties -- finite, no skipped
+    step, deterministic forward, the loss decreases over Adam steps.
+"""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+from conftest import quantised_image, rel_err
+from oracle import nets, ops
+
+pytestmark = pytest.mark.gpu
+LAYER_TOL = 3e-3
+
+
+def dev(x, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda().requires_grad_(grad)
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+CASES = [
+    # name, N, H, W, C1, C2, Cout, k, stride, act, x2_scale
+    ("hal_3x3_64_128_relu", 2, 24, 20, 64, 0, 128, 3, 1, 1, 1.0),
+    ("hal_3x3_128_64", 1, 32, 32, 128, 0, 64, 3, 1, 1, 1.0),
+    ("unet_concat_32_32_64_lrelu", 2, 17, 23, 32, 32, 64, 3, 1, 2, 1.0),
+    ("skip_1x1_64_64_scaled", 2, 16, 16, 64, 64, 64, 1, 1, 0, 1.0 / 255),
+    ("deq_7x7_16_16_lrelu", 1, 32, 32, 16, 0, 16, 7, 1, 2, 1.0),
+    ("deq_5x5_16_32_lrelu", 1, 24, 24, 16, 0, 32, 5, 1, 2, 1.0),
+    ("lin_stem_7x7s2_96_64", 2, 16, 16, 96, 0, 64, 7, 2, 0, 1.0),
+    ("res_1x1s2_256_128", 1, 16, 16, 256, 0, 128, 1, 2, 0, 1.0),
+    ("res_1x1_64_256", 1, 20, 20, 64, 0, 256, 1, 1, 0, 1.0),
+    ("wide_3x3_512_512", 1, 8, 8, 512, 0, 512, 3, 1, 1, 1.0),
+    ("ragged_3x3_16_16", 2, 13, 19, 16, 0, 16, 3, 1, 2, 1.0),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case):
+    name, n, h, w, c1, c2, cout, k, stride, act, x2s = case
+    K = shdr._ops
+    rng = np.random.default_rng(len(name) * 17 + h)
+    x = rng.normal(size=(n, h, w, c1)).astype(np.float32)
+    x2 = (rng.normal(size=(n, h, w, c2)) / x2s).astype(np.float32) if c2 else None
+    wt = (rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2))).astype(np.float32)
+    b = (rng.normal(size=cout) * 0.1).astype(np.float32)
+    ho, wo = -(-h // stride), -(-w // stride)
+    gy = rng.normal(size=(n, ho, wo, cout)).astype(np.float32)
+    # float64 reference with autograd (pinned to the NumPy oracle below and in tests/test_oracle_grad.py)
+    tx, tw, tb = R.T(x, True), R.T(wt, True), R.T(b, True)
+    tx2 = R.T(x2, True) if c2 else None
+    xin = tx if tx2 is None else torch.cat([tx, tx2 * x2s], -1)
+    z = R.conv2d(xin, tw, tb, stride)
+    y = {0: z, 1: torch.relu(z), 2: R.lrelu(z), 3: torch.tanh(z)}[act]
+    np_in = x.astype(np.float64) if c2 == 0 else np.concatenate([x, x2 * np.float32(x2s)], -1).astype(np.float64)
+    np.testing.assert_allclose(z.detach().numpy(), ops.conv2d(np_in, wt.astype(np.float64), b.astype(np.float64), stride),
+                               rtol=1e-9, atol=1e-9)
+    (y * R.T(gy)).sum().backward()
+    # HIP, fp16 MFMA conv path
+    dx, dw, db = dev(x, True), dev(wt, True), dev(b, True)
+    dx2 = dev(x2, True) if c2 else None
+    with K.precision("fp16"):
+        yy = K.conv2d(dx, dw, db, stride=stride, x2=dx2, x2_scale=x2s, act1=act)
+        assert rel_err(host(yy), y.detach().numpy()) <= LAYER_TOL
+        (yy.float() * dev(gy)).sum().backward()
+    assert rel_err(host(dx.grad), tx.grad.numpy()) <= LAYER_TOL, "dx"
+    if c2:
+        assert rel_err(host(dx2.grad), tx2.grad.numpy()) <= LAYER_TOL, "dx2"
+    assert rel_err(host(dw.grad), tw.grad.numpy()) <= LAYER_TOL, "dw"
+    assert rel_err(host(db.grad), tb.grad.numpy()) <= LAYER_TOL, "db"
+
+
+@pytest.fixture(scope="module")
+def ft16(shdr, emor_table):
+    rng = np.random.default_rng(12)
+    P = {k: nets.init_params(getattr(nets, k + "_spec")(), 95 + i) for i, k in enumerate(("deq", "lin", "hal", "ref"))}
+    ldr = quantised_image(rng, (2, 64, 64, 3))
+    ldr[0, :12, :12] = 1.0
+    hdr = rng.random((2, 64, 64, 3)) * 1.5
+    hdr = hdr / (1e-6 + hdr.mean(axis=(1, 2, 3), keepdims=True)) * 0.5
+    mods = dict(deq="dequantization_net", lin="linearization_net", hal="hallucination_net", ref="refinement_net")
+    ms = {k: getattr(shdr, mods[k]).model().load_numpy(P[k]) for k in mods}
+    step = shdr.pipeline.FinetuneStep(ms["deq"], ms["lin"], ms["hal"], ms["ref"], lr=1e-4, precision="fp16", loss_scale=0.25)
+    tP = {k: R.params_to_torch(v) for k, v in P.items()}
+    ref = R.finetune_forward(tP, R.T(ldr), R.T(hdr), emor_table)
+    ref["loss"].sum().backward()
+    return dict(step=step, ms=ms, ldr=dev(ldr), hdr=dev(hdr), ref=ref, tP=tP, P=P, np=(ldr, hdr))
+
+
+def test_fp16_finetune_step_vs_float64_oracle(ft16, emor_table):
+    out = ft16["step"](ft16["ldr"], ft16["hdr"], apply=False)
+    assert ft16["step"].skipped_steps == 0
+    oracle = nets.finetune_forward(ft16["P"], ft16["np"][0], ft16["np"][1], emor_table)      # the NumPy float64 oracle
+    for k in ("C_pred", "B_pred", "A_pred", "refinement_output"):
+        assert rel_err(host(out[k]), oracle[k]) <= 2e-2, k
+    assert rel_err(host(out["loss_sum"]), oracle["loss"].sum(axis=(1, 2, 3))) <= 1e-2
+    # gradients: float64 autograd reference (tests/torch_ref.py, pinned to the NumPy oracle at 1e-9)
+    got = ft16["step"].params.grad.double().cpu().numpy()
+    ref = np.zeros_like(got)
+    for v, o in zip(ft16["step"].params.variables, ft16["step"].params.offsets):
+        pass
+    names = [(net, n) for net in ("deq", "lin", "hal", "ref") for n, _, tr in ft16["ms"][net].named_weights() if tr]
+    for (net, n), o in zip(names, ft16["step"].params.offsets):
+        g = ft16["tP"][net][n].grad.numpy().ravel()
+        ref[o:o + g.size] = g
+    assert np.isfinite(got).all()
+    cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
+    assert cos >= 0.95, cos
+    assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1.0) <= 0.1
+
+
+def test_fp16_finetune_1024_tiles_properties(shdr):
+    """configs[4] at its own size: batch 4 of 1024 x 1024 tiles, fp16 conv path, loss scale 0.25 (bench.py's setting)."""
+    torch.manual_seed(777)
+    g = torch.Generator().manual_seed(5)
+    b, sz = 4, 1024
+    ldr = (torch.round(torch.rand((b, sz, sz, 3), generator=g) * 255.0) / 255.0).cuda()
+    hdr = torch.rand((b, sz, sz, 3), generator=g) * 1.5
+    hdr = (hdr / (1e-6 + hdr.mean(dim=(1, 2, 3), keepdim=True)) * 0.5).cuda()
+    nets4 = [shdr.dequantization_net.model(), shdr.linearization_net.model(), shdr.hallucination_net.model(),
+             shdr.refinement_net.model()]
+    step = shdr.pipeline.FinetuneStep(*nets4, precision="fp16", loss_scale=0.25, lr=1e-4)
+    o1 = step(ldr, hdr, apply=False)
+    g1 = step.params.grad.clone()
+    o2 = step(ldr, hdr, apply=False)
+    for k in ("C_pred", "B_pred", "A_pred", "refinement_output"):
+        assert bool(torch.isfinite(o1[k]).all()), k
+        assert torch.equal(o1[k], o2[k]), k                       # the forward has no atomics: bit-reproducible
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0.0
+    # (the backward accumulates weight gradients with fp32 atomics: reproducible to rounding, not bit for bit)
+    assert float((step.params.grad - g1).norm() / g1.norm()) <= 1e-3
+    first = float(o1["loss_sum"].sum())
+    for _ in range(3):
+        last = float(step(ldr, hdr)["loss_sum"].sum())
+    assert step.skipped_steps == 0
+    assert np.isfinite(last) and last < first, (first, last)
+    assert tuple(o1["refinement_output"].shape) == (b, sz, sz, 3)

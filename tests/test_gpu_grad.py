@@ -295,6 +295,51 @@ def test_hallucination_net_gradients_training_bn(shdr):
     assert e2 <= NET_L2_TOL, (n2, e2, nm, em)
 
 
+def test_inference_mode_networks_under_a_tape(shdr, emor_table):
+    """`net(x, training=False)` while gradients are recorded (fine-tuning with frozen BatchNorm statistics): the fused inference
+    epilogues (folded BN, residual join, second activation) are recorded as conv + affine / join / activation entries, so the
+    result stays on the graph and every variable -- the zero-padded 93 -> 96 channel stem filter included -- receives its
+    gradient.  (Before: the fused kernel ran on detached tensors and silently cut the graph at the first conv + BN.)"""
+    K = shdr._ops
+    rng = np.random.default_rng(5)
+    # Linearization-Net, moving statistics
+    p = nets.init_params(nets.lin_spec(), 64)
+    m = shdr.linearization_net.model().load_numpy(p)
+    x = quantised_image(rng, (2, 64, 64, 3))
+    inv = np.cumsum(rng.random((2, 1024)), axis=1)
+    inv /= inv[:, -1:]
+    tp = R.params_to_torch(p)
+    tinv = R.lin_forward(tp, R.T(x), emor_table, False)
+    ((tinv - R.T(inv)) ** 2).mean(dim=1).sum().backward()
+    pred = m(dev(x), training=False)
+    assert pred.requires_grad and rel_err(host(pred), tinv.detach().numpy()) <= TOL
+    with torch.no_grad():
+        assert rel_err(host(m(dev(x), training=False)), host(pred)) <= 1e-5        # same numbers as the fused inference kernels
+    K.diff_loss(pred, dev(inv), 0).sum().backward()
+    named = dict((n, t) for n, t, tr in m.named_weights() if tr)
+    assert all(t.grad is not None for t in named.values())
+    stem = named["crf_feature_net.conv1.kernel"] if "crf_feature_net.conv1.kernel" in named else next(t for n, t in named.items() if n.endswith("conv1.kernel") and t.shape[2] == 93)
+    assert float(stem.grad.abs().max()) > 0.0
+    (n2, e2), (nm, em) = _grad_check(m, tp)
+    assert e2 <= NET_L2_TOL, (n2, e2, nm, em)
+    # Hallucination-Net, moving statistics (3-channel BN + relu head included)
+    p = nets.init_params(nets.hal_spec(), 65)
+    m = shdr.hallucination_net.model().load_numpy(p)
+    x, tgt = quantised_image(rng, (1, 64, 64, 3)), rng.random((1, 64, 64, 3))
+    tp = R.params_to_torch(p)
+    ty = R.hal_forward(tp, R.T(x), False)
+    (ty - R.T(tgt)).abs().mean(dim=(1, 2, 3)).sum().backward()
+    y = m(dev(x), training=False)
+    assert y.requires_grad and rel_err(host(y), ty.detach().numpy()) <= TOL
+    K.diff_loss(y, dev(tgt), 1).sum().backward()
+    (n2, e2), (nm, em) = _grad_check(m, tp)
+    assert e2 <= NET_L2_TOL, (n2, e2, nm, em)
+    # raw-kernel options cannot be taped: loud, not silent
+    w = dev(rng.normal(size=(3, 3, 16, 16)), True)
+    with pytest.raises(NotImplementedError):
+        K.conv2d(dev(rng.normal(size=(1, 8, 8, 16))), w, pad=(1, 1), out_hw=(8, 8))
+
+
 def test_training_gradients_are_mask_flip_sensitive(shdr):
     """Documents WHY whole-net gradient parity is stated in L2 at the percent level: on the same kernels a
     1e-6 relative perturbation of the input moves the gradients of the randomly initialised, training-mode

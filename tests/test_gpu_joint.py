@@ -53,9 +53,14 @@ def setup(shdr, emor_table):
 
 def test_joint_losses_match_reference(setup):
     out = setup["step"](setup["batch"], setup["inv"], apply=False)
-    for k in ("loss_deq", "loss_lin", "loss_hal", "total"):
-        assert rel_err(host(out[k]), setup["ref"][k].detach().numpy()) <= 1e-4, k
-    assert float(out["total"][-1]) == 0.0                       # masked sample contributes nothing but TV*0
+    b = setup["batch"][0].shape[0]
+    assert tuple(out["loss_lin"].shape) == (b, 1, b, 1) == tuple(out["total"].shape)     # the reference's broadcast (:158-160,183)
+    for k in ("loss_deq", "loss_lin", "loss_hal", "total", "crf_loss"):
+        want = setup["ref"][k].detach().numpy()
+        assert rel_err(host(out[k]).reshape(want.shape), want) <= 1e-4, k
+    assert float(out["total"][-1].abs().max()) == 0.0           # row of the masked sample: nothing but TV * 0
+    # what is differentiated is the sum over the [b,1,b,1] tensor
+    assert abs(float(out["objective"]) - float(out["total"].sum())) <= 1e-5 * abs(float(out["total"].sum()))
     for k in ("C_pred", "B_pred", "A_pred"):
         assert rel_err(host(out[k]), setup["ref"][k].detach().numpy()) <= 1e-4, k
 
@@ -120,7 +125,8 @@ def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     a = fresh()
     joint = shdr.pipeline.JointTrainStep(a["deq"], a["lin"], a["hal"], vgg, multi_stream=False)
     jout = joint((ldr, jpeg, clipped, hdr_t, mask), dev(inv), apply=False)
-    jgrad = {k: torch.cat([t.grad.reshape(-1) for t in a[k].trainable_variables]).clone() for k in mods}
+    # the joint step differentiates the sum over its broadcast [b,1,b,1] loss: every per-sample term carries the factor b
+    jgrad = {k: torch.cat([t.grad.reshape(-1) for t in a[k].trainable_variables]).clone() / float(ldr.shape[0]) for k in mods}
 
     b = fresh()
     s_deq = shdr.pipeline.TrainStep("deq", b["deq"])
@@ -142,11 +148,8 @@ def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     b_pred, crf_mean = s_lin((ldr, clipped, mask, dev(inv)), apply=False)
     assert torch.equal(b_pred, jout["B_pred"])
     tP = R.params_to_torch(P["lin"])
-    t_inv = R.lin_forward(tP, R.T(batch[0]), emor_table, True)
-    t_b = R.apply_rf(R.T(batch[0]), t_inv)
-    crf = ((t_inv - R.T(inv)) ** 2).mean(dim=1)
-    l2 = ((t_b - R.T(batch[2])) ** 2).mean(dim=(1, 2, 3))
-    want = (l2 + 0.1 * crf) * R.T(batch[4]).reshape(-1)
+    want, crf, t_b2 = R.lin_train_loss(tP, R.T(batch[0]), R.T(batch[2]), R.T(batch[4]), R.T(inv), emor_table)
+    assert tuple(want.shape) == (2, 1, 2, 1) == tuple(s_lin.last_loss.shape)   # train.py:189-191 broadcasts like the joint step
     assert rel_err(host(s_lin.last_loss), want.detach().numpy()) <= 1e-4
     assert abs(float(crf_mean) - float(crf.mean())) <= 1e-4 * float(crf.mean())
     want.sum().backward()

@@ -32,7 +32,8 @@ def build(shdr, name, seed):
 def test_dequantization_net_parity(shdr, hw):
     m, p = build(shdr, "deq", 21)
     x = quantised_image(np.random.default_rng(1), (2,) + hw + (3,))
-    y = m(dev(x), training=False)
+    with torch.no_grad():                        # the inference path proper: fused epilogues (tanh + residual add in the last conv)
+        y = m(dev(x), training=False)
     ref = nets.deq_forward(p, x)
     assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
 
@@ -52,7 +53,8 @@ def test_refinement_net_parity(shdr):
 def test_hallucination_net_parity(shdr):
     m, p = build(shdr, "hal", 23)
     x = quantised_image(np.random.default_rng(3), (1, 64, 96, 3))
-    y = host(m(dev(x), training=False))
+    with torch.no_grad():                        # fused folded-BN / relu epilogues, conv + max-pool pairs in one launch
+        y = host(m(dev(x), training=False))
     ref = nets.hal_forward(p, x)
     assert (y >= 0).all() and rel_err(y, ref) <= TOL
 
@@ -60,7 +62,8 @@ def test_hallucination_net_parity(shdr):
 def test_linearization_net_parity(shdr, emor_table):
     m, p = build(shdr, "lin", 24)
     x = quantised_image(np.random.default_rng(4), (2, 64, 64, 3))
-    y = host(m(dev(x), training=False))
+    with torch.no_grad():                        # fused folded-BN / residual / relu epilogues
+        y = host(m(dev(x), training=False))
     ref = nets.lin_forward(p, x, emor_table)
     assert y.shape == (2, 1024) and rel_err(y, ref) <= TOL
     assert (y[:, 0] == 0).all() and (np.diff(y, axis=1) >= 0).all()

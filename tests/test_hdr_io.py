@@ -70,3 +70,21 @@ def test_symmetric_pad_and_image_reader(tmp_path):
     Image.fromarray(rgb[..., 0]).save(str(tmp_path / "g.jpg"), quality=95)
     g = IO.read_ldr(str(tmp_path / "g.jpg"))
     assert g.shape == (20, 30, 3) and g.dtype == np.uint8 and np.array_equal(g[..., 0], g[..., 2])
+
+
+def test_image_reader_applies_exif_orientation(tmp_path):
+    """cv2.imread (test_real_refinement.py:124) applies the EXIF Orientation tag by default; so does read_ldr.
+    Orientation 6 = "rotate 90 degrees clockwise to display": a stored [H, W] image comes back as [W, H]."""
+    from PIL import Image
+    rgb = np.zeros((16, 32, 3), dtype=np.uint8)
+    rgb[:, :16, 0] = 255                                  # left half red, right half blue: lossless to tell apart after JPEG
+    rgb[:, 16:, 2] = 255
+    im = Image.fromarray(rgb)
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    im.save(str(tmp_path / "rot.jpg"), quality=100, subsampling=0, exif=exif.tobytes())
+    im.save(str(tmp_path / "plain.jpg"), quality=100, subsampling=0)
+    plain, rot = IO.read_ldr(str(tmp_path / "plain.jpg")), IO.read_ldr(str(tmp_path / "rot.jpg"))
+    assert plain.shape == (16, 32, 3) and rot.shape == (32, 16, 3)
+    assert np.array_equal(rot, np.rot90(plain, k=-1))     # clockwise quarter turn of the stored pixels
+    assert rot[0, 0, 0] > 200 and rot[-1, 0, 2] > 200     # red (stored left) on top, blue at the bottom

@@ -32,7 +32,7 @@ def test_torch_ref_joint_losses_equal_numpy_oracle(emor_table):
     clipped = quantised_image(rng, (b, s, s, 3))
     clipped[0, :6, :6] = 1.0
     batch = (quantised_image(rng, (b, s, s, 3)), quantised_image(rng, (b, s, s, 3)), clipped,
-             clipped * (1 + 3 * rng.random((b, s, s, 3)) * (clipped >= 1.0)), np.array([1.0, 1.0]).reshape(b, 1, 1, 1))
+             clipped * (1 + 3 * rng.random((b, s, s, 3)) * (clipped >= 1.0)), np.array([1.0, 0.0]).reshape(b, 1, 1, 1))
     inv = np.cumsum(rng.random((b, 1024)), axis=1)
     inv = inv / inv[:, -1:]
     P = {k: nets.init_params(getattr(nets, k + "_spec")(), 50 + i) for i, k in enumerate(("deq", "lin", "hal"))}
@@ -40,8 +40,23 @@ def test_torch_ref_joint_losses_equal_numpy_oracle(emor_table):
     ref = nets.joint_losses(P, V, batch, inv, emor_table)
     out = R.joint_losses({k: R.params_to_torch(v) for k, v in P.items()}, R.params_to_torch(V, False),
                          tuple(R.T(t) for t in batch), R.T(inv), emor_table)
-    for k in ("loss_deq", "loss_lin", "loss_hal", "total"):
-        np.testing.assert_allclose(_np(out[k]), ref[k].reshape(-1), rtol=1e-9, atol=1e-10, err_msg=k)
+    for k in ("loss_deq", "loss_lin", "loss_hal", "total", "crf_loss"):
+        assert tuple(out[k].shape) == ref[k].shape, k
+        np.testing.assert_allclose(_np(out[k]), ref[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    # the reference's shapes (joint_training.py:152-160,182-183): per-sample terms [b,1,1,1], crf_loss [b,1], and therefore
+    # loss_lin / total_loss broadcast to [b,1,b,1]; what tape.gradient differentiates is the sum over all b*b elements
+    assert ref["loss_deq"].shape == (b, 1, 1, 1) and ref["crf_loss"].shape == (b, 1)
+    assert ref["loss_lin"].shape == (b, 1, b, 1) and ref["total"].shape == (b, 1, b, 1)
+    mask = batch[4].reshape(-1)
+    l2 = ((ref["B_pred"] - batch[2]) ** 2).mean(axis=(1, 2, 3))
+    for i in range(b):
+        for j in range(b):
+            want = mask[i] * (10.0 * l2[i] + ref["crf_loss"][j, 0])
+            assert abs(ref["loss_lin"][i, 0, j, 0] - want) <= 1e-12 * max(1.0, abs(want))
+    closed = (b * (ref["loss_deq"].sum() + (10.0 * l2 * mask).sum() + ref["loss_hal"].sum()) + mask.sum() * ref["crf_loss"].sum())
+    assert abs(ref["total"].sum() - closed) <= 1e-12 * abs(closed)
+    # a masked sample (mask[1] = 0) still receives crf gradient: d total.sum() / d crf_1 = sum(mask) = 1, not b * mask_1 = 0
+    out["total"].sum().backward()
 
 
 def test_increase_and_apply_rf_match_oracle():

@@ -214,26 +214,39 @@ def tv_loss(y):
 
 
 def joint_losses(params, vgg_params, batch, invcrf_gt, table, thr=0.12):
-    """joint_training.py:137-183 with training-mode BN; every tensor float64."""
+    """joint_training.py:137-183 with training-mode BN; every tensor float64, shapes as in the reference: the per-sample terms
+    are [b,1,1,1], crf_loss is [b,1], so loss_lin and total broadcast to [b,1,b,1] (see oracle.nets.joint_losses)."""
     ldr, jpeg, clipped, hdr_t, mask = batch
-    m = mask.reshape(-1)
+    m = mask.reshape(-1, 1, 1, 1)
+
+    def per(t):
+        return t.mean(dim=(1, 2, 3), keepdim=True)
     alpha = alpha_mask(clipped, thr)
     c_pred = torch.clamp(deq_forward(params["deq"], jpeg), 0, 1)
-    loss_deq = ((c_pred - ldr) ** 2).mean(dim=(1, 2, 3)) * m
+    loss_deq = per((c_pred - ldr) ** 2) * m
     pred_invcrf = lin_forward(params["lin"], ldr, table, True)
     b_pred = apply_rf(ldr, pred_invcrf)
-    crf_loss = ((pred_invcrf - invcrf_gt) ** 2).mean(dim=1)
-    loss_lin = (10.0 * ((b_pred - clipped) ** 2).mean(dim=(1, 2, 3)) + crf_loss) * m
+    crf_loss = ((pred_invcrf - invcrf_gt) ** 2).mean(dim=1, keepdim=True)
+    loss_lin = (10.0 * per((b_pred - clipped) ** 2) + crf_loss) * m
     hal = hal_forward(params["hal"], clipped, True)
     a_pred = clipped + alpha * hal.flip(-1)
     ya, yh = logc(a_pred), logc(hdr_t)
     perc = 0
     for fa, fb in zip(vgg_forward(vgg_params, ya), vgg_forward(vgg_params, yh)):
-        perc = perc + (fa - fb).abs().mean(dim=(1, 2, 3))
-    l1 = (ya - yh).abs().mean(dim=(1, 2, 3))
+        perc = perc + per((fa - fb).abs())
+    l1 = per((ya - yh).abs())
     loss_hal = (l1 + 0.001 * perc + 0.1 * tv_loss(ya)) * m
     return dict(total=loss_deq + loss_lin + loss_hal, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
                 crf_loss=crf_loss, C_pred=c_pred, B_pred=b_pred, A_pred=a_pred)
+
+
+def lin_train_loss(params, ldr, clipped, mask, invcrf_gt, table):
+    """train.py:183-191: (l2 [b,1,1,1] + 0.1 * crf_loss [b,1]) * loss_mask -> [b,1,b,1], the same broadcast"""
+    pred_invcrf = lin_forward(params, ldr, table, True)
+    b_pred = apply_rf(ldr, pred_invcrf)
+    crf_loss = ((pred_invcrf - invcrf_gt) ** 2).mean(dim=1, keepdim=True)
+    l2 = ((b_pred - clipped) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    return (l2 + 0.1 * crf_loss) * mask.reshape(-1, 1, 1, 1), crf_loss, b_pred
 
 
 def ref_forward(p, x):
