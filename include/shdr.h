@@ -350,6 +350,64 @@ int shdr_jpeg_round_trip_f32(const float* ldr, const int32_t* quality, float* jp
 int shdr_flip_rot90_f32(const float* x, float* y, const int32_t* flip, const int32_t* rot, int N, int S, int C,
                         float divisor, void* stream);
 
+
+/* ---- native-fp16 activation path: BASELINE configs[4] ("finetune_real_dataset.py with Refinement-Net, 1024x1024 tiles,
+ *      fp16 MFMA conv path").  Feature maps are NHWC fp16 (`void*` = _Float16 / IEEE binary16) with C % 8 == 0, image-like
+ *      3-channel tensors and every parameter / parameter gradient stay fp32, accumulation is fp32.  These are the `_f16` twins of
+ *      the entry points above and replace the same TF call sites (finetune_real_dataset.py:144-178). ---- */
+/* number of fp16 elements of the packed filter of a [KH,KW,C1+C2,Cout] conv */
+int64_t shdr_conv2d_packed_filter_elems_f16(int KH, int KW, int C1, int C2, int Cout);
+/* fp32 HWIO filter -> packed fp16 [k-chunk][Cout][32] in the k order of shdr_conv2d_fwd_f16; x2_scale is folded into the rows of
+ * the second source (hallucination_net.py:101) */
+int shdr_conv2d_pack_filter_f16(const float* w, void* wp, int KH, int KW, int C1, int C2, int Cout, float x2_scale, void* stream);
+/* y = act1(conv(concat[x1, x2], wp) + bias): tf.keras.layers.Conv2D forward, and -- run on dZ with the flipped / transposed
+ * filter -- GradientTape.gradient w.r.t. its input.  d->C1 % 8 == d->C2 % 8 == 0, d->Cout % 16 == 0; y fp16 [N,Ho,Wo,Cout], or
+ * fp32 [N,Ho,Wo,cout_valid] when y_is_f32 (the 3-channel heads); scale / shift / residual / act2 of the desc are not used. */
+int shdr_conv2d_fwd_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias, void* y,
+                        int y_is_f32, void* stream);
+/* dw[kh][kw][ci_off + ci][co] += scale * sum_p x[p + tap][ci] * dz[p][co]  (fp32, accumulated with atomics; the caller zeroes dw).
+ * x = source `which` of the forward conv `d` (d->C1 / d->C2 = channels per pixel of the fp16 tensors, possibly zero-padded),
+ * dz fp16 with dz_channels per pixel; dw = [KH,KW,c1_rows + c2_rows, d->Cout], of which the first cout_valid columns are written. */
+int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels, int c1_rows,
+                          int c2_rows, float* dw, void* stream);
+int shdr_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+int shdr_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* fp32 [npix, Cin] -> fp16 [npix, Cout] zero-padded (narrow gradients of the 3-channel heads onto 8-channel groups) */
+int shdr_pad_channels_f32_to_f16(const float* x, void* y, int64_t npix, int Cin, int Cout, void* stream);
+/* tf.concat of up to four 3-channel fp32 images -> fp16 [npix, out_channels] (zero-padded; test_real_refinement.py:108);
+ * vgg_preprocess: x*255, RGB->BGR, minus mean of hallucination_net.py:149-153 on the single source */
+int shdr_pack3_f16(const float* s0, const float* s1, const float* s2, const float* s3, int nsrc, void* y, int out_channels,
+                   int64_t npix, int vgg_preprocess, void* stream);
+/* its backward: the first nout 3-channel slices of fp16 y [npix, channels] -> fp32 images */
+int shdr_unpack3_f16(const void* y, float* o0, float* o1, float* o2, float* o3, int nout, int channels, int64_t npix,
+                     int vgg_preprocess_bwd, void* stream);
+/* dz = dy * act'(y) (skipped for act NONE), db[c] += sum_p dz[p][c] (skipped when db is NULL) */
+int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, float* db, int64_t npix, int C, int act, void* stream);
+/* y = a + b, optionally relu (residual joins of linearization_net.py:45-47,80-82; gradient accumulation at fan-out points) */
+int shdr_add_f16(const void* a, const void* b, void* y, int64_t n, int relu, void* stream);
+int shdr_avgpool2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int shdr_avgpool2_bwd_f16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int shdr_maxpool2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int shdr_maxpool2_bwd_f16(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int shdr_maxpool3s2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int shdr_maxpool3s2_bwd_f16(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int shdr_resize2x_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int shdr_resize2x_bwd_f16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int shdr_upsample_zero2_f16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* tf.reduce_mean(x,[1,2]): fp16 [N,HW,C] -> fp32 [N,C], and its backward (fp32 dy -> fp16 dx) */
+int shdr_gap_fwd_f16(const void* x, float* y, int N, int HW, int C, void* stream);
+int shdr_gap_bwd_f16(const float* dy, void* dx, int N, int HW, int C, void* stream);
+/* training-mode BatchNormalization on fp16 tensors; statistics, parameters and their gradients fp32 (sums in double) */
+int shdr_bn_stats_f16(const void* x, double* ws, float* mean, float* var, float* moving_mean, float* moving_var, int64_t npix, int C,
+                      float momentum, void* stream);
+int shdr_bn_train_apply_f16(const void* x, const float* mean, const float* var, const float* gamma, const float* beta, void* y,
+                            int64_t npix, int C, float eps, int relu, void* stream);
+int shdr_bn_bwd_f16(const void* dy, const void* x, const void* y_relu, const float* mean, const float* var, const float* gamma,
+                    double* ws, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, float eps, void* stream);
+/* Linearization-Net front end (linearization_net.py:310-322) fp32 image -> fp16 [N,H,W,y_channels >= 93], and its backward */
+int shdr_lin_frontend_fwd_f16(const float* img, void* y, int N, int H, int W, int y_channels, void* stream);
+int shdr_lin_frontend_bwd_f16(const float* img, const void* dF, float* dimg, int N, int H, int W, int y_channels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

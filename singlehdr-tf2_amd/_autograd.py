@@ -82,7 +82,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, bias, stride, x2_scale, act1, cout_valid, algo):
         wf = w
-        if K.PRECISION != "fp32" and x2 is not None and x2_scale != 1.0:
+        if K.PRECISION in ("fp16op", "bf16") and x2 is not None and x2_scale != 1.0:
             # the reduced-precision kernels take x2_scale folded into the x2 rows of the filter
             c1 = x.shape[3]
             wf = torch.cat([w[:, :, :c1], w[:, :, c1:] * x2_scale], dim=2)
@@ -128,6 +128,102 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=K.ACT_NONE, sc
         raise NotImplementedError("the fused inference epilogue (folded BN / residual / act2) is not differentiable; "
                                   "the training path applies these as separate ops")
     return Conv2dFn.apply(x, x2, w, bias, stride, x2_scale, act1, cout_valid, algo)
+
+
+# ---------------------------------------------------------------------------
+# convolution on fp16 feature maps (native-fp16 path of BASELINE configs[4])
+# ---------------------------------------------------------------------------
+def _dgrad_h(dz, w, c_begin, c_count, scale, stride, x_shape):
+    """fp16 input gradient w.r.t. source channels [c_begin, c_begin + c_count) of the forward filter w (fp32 HWIO): the fp16
+    conv kernel run on dz with the flipped / transposed filter -- same decomposition as _dgrad (stride 1; 1x1 / 2 on the coarse
+    grid; general stride 2 in polyphase form)"""
+    kh, kw = w.shape[0], w.shape[1]
+    cz = dz.shape[3]                                   # channels per pixel of dz (>= the filter's true output channels)
+    cols = min(w.shape[3], cz)
+    if w.shape[3] != cols:                             # zero-padded filter columns carry no gradient
+        w = w[..., :cols].contiguous()
+    wt = K.filter_transform(w, c_begin, c_count, scale)            # fp32 [kh, kw, cols, c_count]
+    if cz != cols or c_count % 16:
+        wt = F.pad(wt, (0, (-c_count) % 16, 0, cz - cols))
+    if c_count % 16:
+        raise NotImplementedError("fp16 input gradient needs a multiple of 16 input channels, got %d" % c_count)
+
+    def run(filt, **kw_):
+        return K.conv2d_h(dz, K.pack_filter_h(filt, cz), None, tuple(filt.shape[:2]), filt.shape[3], **kw_)
+    if stride == 1:
+        return run(wt)
+    if stride == 2 and kh == 1 and kw == 1:
+        return K.upsample_zero2(run(wt), x_shape)
+    if stride == 2:
+        n, h, wd, _ = x_shape
+        _, pt = K.same_pad(h, kh, 2)
+        _, pl = K.same_pad(wd, kw, 2)
+        dx = torch.empty((n, h, wd, c_count), device=dz.device, dtype=dz.dtype)
+
+        def phase(par_in, pad_fwd, k):
+            par = (par_in + pad_fwd) % 2
+            taps = len(range(par, k, 2))
+            off = (par_in + pad_fwd - par) // 2
+            return k - 1 - par - 2 * (taps - 1), taps - 1 - off, taps
+        for p_ in range(2):
+            a0, pad_t, th = phase(p_, pt, kh)
+            mh = (h - p_ + 1) // 2
+            for q_ in range(2):
+                b0, pad_l, tw = phase(q_, pl, kw)
+                mw = (wd - q_ + 1) // 2
+                if mh == 0 or mw == 0:
+                    continue
+                if th == 0 or tw == 0:
+                    dx[:, p_::2, q_::2] = 0.0
+                    continue
+                dx[:, p_::2, q_::2] = run(wt[a0::2, b0::2].contiguous(), pad=(pad_t, pad_l), out_hw=(mh, mw))
+        return dx
+    raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built" % (kh, kw, stride))
+
+
+class Conv2dHFn(torch.autograd.Function):
+    """y = act1(conv(concat[x, x2_scale * x2], w) + bias) with fp16 x / x2 / y, fp32 w / bias and fp32 parameter gradients.
+    A narrow head (cout_valid < w.shape[3], the zero-padded 3-channel outputs) returns fp32."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, bias, stride, x2_scale, act1, cout_valid):
+        c1 = x.shape[3]
+        c2 = 0 if x2 is None else x2.shape[3]
+        wp = K.pack_filter_h(w, c1, c2, x2_scale)
+        y = K.conv2d_h(x, wp, bias, tuple(w.shape[:2]), w.shape[3], stride=stride, x2=x2, act1=act1, cout_valid=cout_valid)
+        ctx.save_for_backward(x, x2, w, y)
+        ctx.meta = (stride, x2_scale, act1, bias is not None, cout_valid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w, y = ctx.saved_tensors
+        stride, x2_scale, act1, has_bias, cout_valid = ctx.meta
+        dy = _c(dy)
+        need_x, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
+        db = None
+        if y.dtype == torch.float32:                   # head: the 3-channel gradient is fp32; pad it onto an 8-channel fp16 group
+            dz32 = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
+            if need_b and has_bias:
+                db = K.bias_grad(dz32)
+            dz = K.pad_channels_h(dz32, 8)
+            cols = y.shape[3]
+        else:
+            dz, db = K.act_bwd_bias_h(dy, y, act1, need_b and has_bias)
+            cols = None
+        dx = dx2 = dw = None
+        c1 = x.shape[3]
+        if need_w:
+            dw = K.conv2d_wgrad_h(x, x2, dz, tuple(w.shape), stride, x2_scale, cout_valid=cols)
+        if need_x:
+            dx = _dgrad_h(dz, w, 0, c1, 1.0, stride, x.shape)
+        if need_x2 and x2 is not None:
+            dx2 = _dgrad_h(dz, w, c1, x2.shape[3], x2_scale, stride, x2.shape)
+        return dx, dx2, dw, db, None, None, None, None
+
+
+def conv2d_h(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=K.ACT_NONE, cout_valid=None):
+    return Conv2dHFn.apply(x, x2, w, bias, stride, x2_scale, act1, cout_valid)
 
 
 # ---------------------------------------------------------------------------
@@ -212,15 +308,15 @@ MaxPool3s2Fn = _simple("MaxPool3s2Fn", lambda x: (K.maxpool3s2(x), (x,), None),
                        lambda s, m, dy: K.maxpool3s2_bwd(s[0], dy))
 Resize2xFn = _simple("Resize2xFn", lambda x: (K.resize2x(x), (), tuple(x.shape)),
                      lambda s, m, dy: K.resize2x_bwd(dy, m))
-GapFn = _simple("GapFn", lambda x: (K.global_avg_pool(x), (), tuple(x.shape)),
-                lambda s, m, dy: K.gap_bwd(dy, m))
+GapFn = _simple("GapFn", lambda x: (K.global_avg_pool(x), (), (tuple(x.shape), x.dtype)),
+                lambda s, m, dy: K.gap_bwd(dy, m[0], m[1]))
 ClipFn = _simple("ClipFn", lambda x, lo, hi: (K.clip(x, lo, hi), (x,), (lo, hi)),
                  lambda s, m, dy: K.clip_bwd(dy, s[0], m[0], m[1]))
 LogcFn = _simple("LogcFn", lambda x: (K.logc(x), (x,), None),
                  lambda s, m, dy: K.logc_bwd(dy, s[0]))
 Reverse3Fn = _simple("Reverse3Fn", lambda x: (K.reverse3(x), (), None),
                      lambda s, m, dy: K.reverse3(dy))
-VggPreFn = _simple("VggPreFn", lambda x, oc: (K.vgg_preprocess(x, oc), (), None),
+VggPreFn = _simple("VggPreFn", lambda x, oc, dt: (K.vgg_preprocess(x, oc, dt), (), None),
                    lambda s, m, dy: K.vgg_preprocess_bwd(dy))
 IncreaseFn = _simple("IncreaseFn", lambda rf: (K.increase(rf), (rf,), None),
                      lambda s, m, dy: K.increase_bwd(s[0], dy))
@@ -258,8 +354,8 @@ def reverse3(x):
     return Reverse3Fn.apply(x)
 
 
-def vgg_preprocess(x, out_channels=3):
-    return VggPreFn.apply(x, out_channels)
+def vgg_preprocess(x, out_channels=3, dtype=torch.float32):
+    return VggPreFn.apply(x, out_channels, dtype)
 
 
 def increase(rf):
@@ -313,7 +409,7 @@ class AddReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        y = K.clip(K.add(a, b), 0.0, float("inf"))
+        y = K.add(a, b, relu=True)
         ctx.save_for_backward(y)
         return y
 
@@ -427,18 +523,18 @@ def blend_const(base, alpha, hal_bgr, thr):
 # ---------------------------------------------------------------------------
 class LinFrontendFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, channels):
+    def forward(ctx, img, channels, dtype):
         ctx.save_for_backward(img)
-        return K.lin_frontend(img, channels)
+        return K.lin_frontend(img, channels, dtype)
 
     @staticmethod
     def backward(ctx, dF):
         (img,) = ctx.saved_tensors
-        return K.lin_frontend_bwd(img, _c(dF)), None
+        return K.lin_frontend_bwd(img, _c(dF)), None, None
 
 
-def lin_frontend(img, channels):
-    return LinFrontendFn.apply(img, channels)
+def lin_frontend(img, channels, dtype=torch.float32):
+    return LinFrontendFn.apply(img, channels, dtype)
 
 
 class AlphaBlendFn(torch.autograd.Function):
@@ -463,28 +559,28 @@ def alpha_blend(b_pred, hal_bgr, thr):
 
 class Pack3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out_channels, *srcs):
+    def forward(ctx, out_channels, dtype, *srcs):
         ctx.n = len(srcs)
-        return K.pack3(list(srcs), out_channels)
+        return K.pack3(list(srcs), out_channels, dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        return (None,) + tuple(K.unpack3(_c(dy), ctx.n))
+        return (None, None) + tuple(K.unpack3(_c(dy), ctx.n))
 
 
-def pack3(srcs, out_channels):
-    return Pack3Fn.apply(out_channels, *srcs)
+def pack3(srcs, out_channels, dtype=torch.float32):
+    return Pack3Fn.apply(out_channels, dtype, *srcs)
 
 
 class Unpack3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, nout):
-        ctx.channels = y.shape[-1]
+        ctx.channels, ctx.dtype = y.shape[-1], y.dtype
         return K.unpack3(y, nout)
 
     @staticmethod
     def backward(ctx, *grads):
-        return K.pack3([_c(g) for g in grads], ctx.channels), None
+        return K.pack3([_c(g) for g in grads], ctx.channels, ctx.dtype), None
 
 
 def unpack3(y, nout):

@@ -104,6 +104,33 @@ SIGNATURES = {
     "shdr_sample_dot_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr]),
     "shdr_mean_norm_fwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f32, c_ptr]),
     "shdr_mean_norm_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f32, c_ptr]),
+    "shdr_conv2d_packed_filter_elems_f16": (c_i64, [c_int] * 5),
+    "shdr_conv2d_pack_filter_f16": (c_int, [c_ptr, c_ptr] + [c_int] * 5 + [c_f32, c_ptr]),
+    "shdr_conv2d_fwd_f16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 5 + [c_int, c_ptr]),
+    "shdr_conv2d_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "shdr_cast_f32_to_f16": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_cast_f16_to_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_pad_channels_f32_to_f16": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
+    "shdr_pack3_f16": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_int, c_ptr]),
+    "shdr_unpack3_f16": (c_int, [c_ptr] * 5 + [c_int, c_int, c_i64, c_int, c_ptr]),
+    "shdr_act_bwd_bias_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
+    "shdr_add_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "shdr_avgpool2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_avgpool2_bwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool2_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_resize2x_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_resize2x_bwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_upsample_zero2_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_gap_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "shdr_gap_bwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "shdr_bn_stats_f16": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_ptr]),
+    "shdr_bn_train_apply_f16": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr]),
+    "shdr_bn_bwd_f16": (c_int, [c_ptr] * 10 + [c_i64, c_int, c_f32, c_ptr]),
+    "shdr_lin_frontend_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_lin_frontend_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_adam_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
 }
 

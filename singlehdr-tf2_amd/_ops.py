@@ -44,11 +44,21 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
 
-# MFMA operand precision of the conv kernels (forward, dgrad, wgrad).  "fp32" is the parity path (exact-fp32 MFMA);
-# "fp16" / "bf16" is the reduced-precision path of BASELINE configs[4]: tensors stay fp32 in HBM, operands are rounded
-# when they are packed for v_mfma_f32_16x16x32_{f16,bf16}, accumulation is fp32.  Winograd is not used then.
+# Precision of the conv path.
+#   "fp32"  : the parity path (exact-fp32 MFMA, Winograd where it pays).
+#   "fp16"  : BASELINE configs[4], NATIVE fp16: the networks turn their inputs into fp16 feature maps (NHWC, C % 8 == 0) and every
+#             conv forward / dgrad / wgrad, BatchNorm, pooling, resize and activation-backward pass reads and writes fp16
+#             (csrc/conv_f16.hip, wgrad_f16.hip, elem_f16.hip); parameters, their gradients, statistics and the 3-channel
+#             image-like tensors stay fp32, accumulation is fp32.  Ops dispatch on the dtype of their input tensor.
+#   "fp16op" / "bf16" : the round-1 operand-rounding modes -- fp32 tensors in HBM, operands rounded when they are packed for
+#             v_mfma_f32_16x16x32_{f16,bf16} (kept for comparison; Winograd is not used then).
 PRECISION = "fp32"
-_AUTO_ALGO = {"fp32": ALGO_AUTO, "fp16": ALGO_AUTO_F16, "bf16": ALGO_AUTO_BF16}
+_AUTO_ALGO = {"fp32": ALGO_AUTO, "fp16": ALGO_AUTO, "fp16op": ALGO_AUTO_F16, "bf16": ALGO_AUTO_BF16}
+
+
+def native_fp16():
+    """True inside `precision("fp16")`: feature maps are created as fp16"""
+    return PRECISION == "fp16"
 
 
 class precision:
@@ -77,16 +87,31 @@ def same_pad(in_size, k, stride):
     return out, total // 2
 
 
-def _chk(t, name):
+def _chk(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s: expected a torch.Tensor" % name)
     if not t.is_cuda:
         raise RuntimeError("%s: tensor is on %s -- the SingleHDR hot path runs only on a HIP device "
                            "(no CPU fallback)" % (name, t.device))
-    if t.dtype != torch.float32:
-        raise TypeError("%s: expected float32, got %s" % (name, t.dtype))
+    if t.dtype != dtype:
+        raise TypeError("%s: expected %s, got %s" % (name, str(dtype).replace("torch.", ""), t.dtype))
     if not t.is_contiguous():
         raise ValueError("%s: tensor must be contiguous NHWC" % name)
+    return t
+
+
+HALF = torch.float16
+
+
+def _is_h(t):
+    return isinstance(t, torch.Tensor) and t.dtype == torch.float16
+
+
+def _chkh(t, name):
+    """fp16 feature map of the native-fp16 path: contiguous NHWC, C % 8 == 0"""
+    t = _chk(t, name, torch.float16)
+    if t.shape[-1] % 8:
+        raise ValueError("%s: fp16 feature maps need C %% 8 == 0, got %d" % (name, t.shape[-1]))
     return t
 
 
@@ -111,6 +136,14 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     `cout_valid` < w.shape[3] says the filter is zero-padded along Cout (to a multiple of 16 so
     that a narrow head runs on the MFMA tile); only the first `cout_valid` channels are stored.
     `pad=(top, left)` / `out_hw=(Ho, Wo)` override the SAME rule (used by the strided dgrad)."""
+    if _is_h(x):
+        if scale is not None or shift is not None or residual is not None or act2 != ACT_NONE or pad is not None or out is not None \
+                or w_batch_stride or algo != ALGO_AUTO:
+            raise NotImplementedError("conv2d: the native-fp16 path takes bias + act1 only (training-mode layers)")
+        if _needs_grad(x, x2, w, bias):
+            return AUTOGRAD.conv2d_h(x, w, bias, stride, x2, x2_scale, act1, cout_valid)
+        return conv2d_h(x, pack_filter_h(w, x.shape[3], 0 if x2 is None else x2.shape[3], x2_scale), bias, tuple(w.shape[:2]),
+                        w.shape[3], stride=stride, x2=x2, act1=act1, cout_valid=cout_valid)
     if algo == ALGO_AUTO:
         algo = _AUTO_ALGO[PRECISION]
     fused = scale is not None or shift is not None or residual is not None or act2 != ACT_NONE
@@ -188,9 +221,13 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
 
 def _nhwc_op(fn_name, x, out_shape):
     lib = _lib.load()
-    x = _chk(_d(x), "x")
+    if _is_h(x):                       # the _f16 twin (csrc/elem_f16.hip)
+        x = _chkh(_d(x), "x")
+        fn_name = fn_name[:-4] + "_f16"
+    else:
+        x = _chk(_d(x), "x")
     n, h, w, c = x.shape
-    y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    y = torch.empty(out_shape, device=x.device, dtype=x.dtype)
     rc = getattr(lib, fn_name)(_ptr(x), _ptr(y), n, h, w, c, _stream())
     _lib.check(rc, fn_name)
     return y
@@ -228,9 +265,12 @@ def global_avg_pool(x):
     if _needs_grad(x):
         return AUTOGRAD.global_avg_pool(x)
     lib = _lib.load()
-    x = _chk(_d(x), "x")
     n, h, w, c = x.shape
     y = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    if _is_h(x):
+        _lib.check(lib.shdr_gap_fwd_f16(_ptr(_chkh(_d(x), "x")), _ptr(y), n, h * w, c, _stream()), "shdr_gap_fwd_f16")
+        return y
+    x = _chk(_d(x), "x")
     _lib.check(lib.shdr_gap_fwd_f32(_ptr(x), _ptr(y), n, h * w, c, _stream()), "shdr_gap_fwd_f32")
     return y
 
@@ -247,17 +287,19 @@ def soft_hist(img, max_bin):
     return y
 
 
-def lin_frontend(img, channels=96):
+def lin_frontend(img, channels=96, dtype=None):
+    """dtype: torch.float16 inside precision("fp16") (native-fp16 feature maps), float32 otherwise"""
+    dtype = dtype or (HALF if native_fp16() else torch.float32)
     if _needs_grad(img):
-        return AUTOGRAD.lin_frontend(img, channels)
+        return AUTOGRAD.lin_frontend(img, channels, dtype)
     lib = _lib.load()
     img = _chk(_d(img), "img")
     n, h, w, c = img.shape
     if c != 3:
         raise ValueError("lin_frontend: expected 3 channels, got %d" % c)
-    y = torch.empty((n, h, w, channels), device=img.device, dtype=torch.float32)
-    _lib.check(lib.shdr_lin_frontend_fwd_f32(_ptr(img), _ptr(y), n, h, w, channels, _stream()),
-               "shdr_lin_frontend_fwd_f32")
+    y = torch.empty((n, h, w, channels), device=img.device, dtype=dtype)
+    fn = "shdr_lin_frontend_fwd_f16" if dtype == HALF else "shdr_lin_frontend_fwd_f32"
+    _lib.check(getattr(lib, fn)(_ptr(img), _ptr(y), n, h, w, channels, _stream()), fn)
     return y
 
 
@@ -331,12 +373,17 @@ def _pix3(x, name):
     return x, x.numel() // 3
 
 
-def vgg_preprocess(x, out_channels=3):
-    """x*255, RGB->BGR, minus VGG mean; out_channels=4 appends a zero channel (MFMA-friendly)."""
+def vgg_preprocess(x, out_channels=3, dtype=torch.float32):
+    """x*255, RGB->BGR, minus VGG mean; out_channels=4 appends a zero channel (MFMA-friendly); dtype float16: the zero-padded
+    fp16 feature map of the native-fp16 path (out_channels % 8 == 0)."""
     if _needs_grad(x):
-        return AUTOGRAD.vgg_preprocess(x, out_channels)
+        return AUTOGRAD.vgg_preprocess(x, out_channels, dtype)
     lib = _lib.load()
     x, npix = _pix3(x, "x")
+    if dtype == HALF:
+        y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=HALF)
+        _lib.check(lib.shdr_pack3_f16(_ptr(x), None, None, None, 1, _ptr(y), out_channels, npix, 1, _stream()), "shdr_pack3_f16")
+        return y
     y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=torch.float32)
     _lib.check(lib.shdr_vgg_preprocess_fwd_f32(_ptr(x), _ptr(y), npix, out_channels, _stream()),
                "shdr_vgg_preprocess_fwd_f32")
@@ -370,9 +417,9 @@ def alpha_blend(b_pred, hal_bgr, thr=0.12, return_alpha=False):
     return (a, alpha) if return_alpha else a
 
 
-def pack3(srcs, out_channels=None):
+def pack3(srcs, out_channels=None, dtype=torch.float32):
     if _needs_grad(*srcs):
-        return AUTOGRAD.pack3(list(srcs), out_channels)
+        return AUTOGRAD.pack3(list(srcs), out_channels, dtype)
     lib = _lib.load()
     srcs = [_pix3(s, "src%d" % i)[0] for i, s in enumerate(srcs)]
     n = len(srcs)
@@ -381,8 +428,11 @@ def pack3(srcs, out_channels=None):
     if any(s.shape != srcs[0].shape for s in srcs):
         raise ValueError("pack3: shape mismatch")
     oc = out_channels or 3 * n
-    y = torch.empty(tuple(srcs[0].shape[:-1]) + (oc,), device=srcs[0].device, dtype=torch.float32)
+    y = torch.empty(tuple(srcs[0].shape[:-1]) + (oc,), device=srcs[0].device, dtype=dtype)
     p = [_ptr(s) for s in srcs] + [None] * (4 - n)
+    if dtype == HALF:
+        _lib.check(lib.shdr_pack3_f16(p[0], p[1], p[2], p[3], n, _ptr(y), oc, srcs[0].numel() // 3, 0, _stream()), "shdr_pack3_f16")
+        return y
     _lib.check(lib.shdr_pack3_fwd_f32(p[0], p[1], p[2], p[3], n, _ptr(y), oc, srcs[0].numel() // 3,
                                       _stream()), "shdr_pack3_fwd_f32")
     return y
@@ -490,6 +540,8 @@ def bias_grad(dz):
 def act_bwd_bias(dy, y, act):
     """(dz, db) of y = act(z + bias): dz = dy * act'(y), db = sum over pixels of dz -- one fused pass when the channel
     count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise"""
+    if _is_h(dy):
+        return act_bwd_bias_h(dy, y, act, True)
     dy = _chk(_d(dy), "dy")
     c = dy.shape[-1]
     q = c // 4
@@ -509,6 +561,8 @@ def act_bwd_bias(dy, y, act):
 
 
 def act_bwd(dy, y, act):
+    if _is_h(dy):
+        return act_bwd_bias_h(dy, y, act, False)[0]
     lib = _lib.load()
     dy, y = _chk(_d(dy), "dy"), _chk(_d(y), "y")
     dx = torch.empty_like(dy)
@@ -524,10 +578,22 @@ def clip_bwd(dy, x, lo, hi):
     return dx
 
 
-def add(a, b):
+def add(a, b, relu=False):
+    """a + b (relu: max(a + b, 0), fp16 feature maps only)"""
     if _needs_grad(a, b):
+        if relu:
+            return AUTOGRAD.add_relu(a, b)
         return AUTOGRAD.add(a, b)
     lib = _lib.load()
+    if _is_h(a):
+        a, b = _chkh(_d(a), "a"), _chkh(_d(b), "b")
+        if a.shape != b.shape:
+            raise ValueError("add: shape mismatch")
+        y = torch.empty_like(a)
+        _lib.check(lib.shdr_add_f16(_ptr(a), _ptr(b), _ptr(y), a.numel(), int(bool(relu)), _stream()), "shdr_add_f16")
+        return y
+    if relu:
+        return clip(add(a, b), 0.0, float("inf"))
     a, b = _chk(_d(a), "a"), _chk(_d(b), "b")
     if a.shape != b.shape:
         raise ValueError("add: shape mismatch")
@@ -557,9 +623,13 @@ def affine_act(x, scale=None, shift=None, residual=None, act=ACT_NONE):
 def _bwd_nhwc(fn_name, x_shape, *tensors):
     """input-gradient kernels taking (tensors..., dx, N, H, W, C) of the op's INPUT shape"""
     lib = _lib.load()
-    ts = [_chk(_d(t), "t%d" % i) for i, t in enumerate(tensors)]
+    if _is_h(tensors[0]):
+        ts = [_chkh(_d(t), "t%d" % i) for i, t in enumerate(tensors)]
+        fn_name = fn_name[:-4] + "_f16"
+    else:
+        ts = [_chk(_d(t), "t%d" % i) for i, t in enumerate(tensors)]
     n, h, w, c = x_shape
-    dx = torch.empty(tuple(x_shape), device=ts[0].device, dtype=torch.float32)
+    dx = torch.empty(tuple(x_shape), device=ts[0].device, dtype=ts[0].dtype)
     _lib.check(getattr(lib, fn_name)(*[_ptr(t) for t in ts], _ptr(dx), n, h, w, c, _stream()), fn_name)
     return dx
 
@@ -584,12 +654,13 @@ def upsample_zero2(dy, x_shape):
     return _bwd_nhwc("shdr_upsample_zero2_f32", x_shape, dy)
 
 
-def gap_bwd(dy, x_shape):
+def gap_bwd(dy, x_shape, dtype=torch.float32):
     lib = _lib.load()
     dy = _chk(_d(dy), "dy")
     n, h, w, c = x_shape
-    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
-    _lib.check(lib.shdr_gap_bwd_f32(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), "shdr_gap_bwd_f32")
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=dtype)
+    fn = "shdr_gap_bwd_f16" if dtype == HALF else "shdr_gap_bwd_f32"
+    _lib.check(getattr(lib, fn)(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), fn)
     return dx
 
 
@@ -600,37 +671,43 @@ def _bn_ws(c, device):
 def bn_stats(x, moving_mean=None, moving_var=None, momentum=0.99):
     """batch mean / biased variance over (N,H,W); optionally updates the moving statistics in place."""
     lib = _lib.load()
-    x = _chk(_d(x), "x")
+    h = _is_h(x)
+    x = _chkh(_d(x), "x") if h else _chk(_d(x), "x")
     c = x.shape[-1]
     mean = torch.empty(c, device=x.device, dtype=torch.float32)
     var = torch.empty(c, device=x.device, dtype=torch.float32)
     ws = _bn_ws(c, x.device)
-    _lib.check(lib.shdr_bn_stats_f32(_ptr(x), _ptr(ws), _ptr(mean), _ptr(var), _ptr(_d(moving_mean)), _ptr(_d(moving_var)),
-                                     x.numel() // c, c, float(momentum), _stream()), "shdr_bn_stats_f32")
+    fn = "shdr_bn_stats_f16" if h else "shdr_bn_stats_f32"
+    _lib.check(getattr(lib, fn)(_ptr(x), _ptr(ws), _ptr(mean), _ptr(var), _ptr(_d(moving_mean)), _ptr(_d(moving_var)),
+                                x.numel() // c, c, float(momentum), _stream()), fn)
     _mutated(moving_mean, moving_var)
     return mean, var
 
 
 def bn_train_apply(x, mean, var, gamma, beta, eps, relu):
     lib = _lib.load()
-    x = _chk(_d(x), "x")
+    h = _is_h(x)
+    x = _chkh(_d(x), "x") if h else _chk(_d(x), "x")
     c = x.shape[-1]
     y = torch.empty_like(x)
-    _lib.check(lib.shdr_bn_train_apply_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
-                                           x.numel() // c, c, float(eps), int(bool(relu)), _stream()), "shdr_bn_train_apply_f32")
+    fn = "shdr_bn_train_apply_f16" if h else "shdr_bn_train_apply_f32"
+    _lib.check(getattr(lib, fn)(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
+                                x.numel() // c, c, float(eps), int(bool(relu)), _stream()), fn)
     return y
 
 
 def bn_bwd(dy, x, y_relu, mean, var, gamma, eps):
     lib = _lib.load()
-    dy, x = _chk(_d(dy), "dy"), _chk(_d(x), "x")
+    h = _is_h(x)
+    dy, x = (_chkh(_d(dy), "dy"), _chkh(_d(x), "x")) if h else (_chk(_d(dy), "dy"), _chk(_d(x), "x"))
     c = x.shape[-1]
     dgamma = torch.zeros(c, device=x.device, dtype=torch.float32)
     dbeta = torch.zeros(c, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     ws = _bn_ws(c, x.device)
-    _lib.check(lib.shdr_bn_bwd_f32(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
-                                   _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _stream()), "shdr_bn_bwd_f32")
+    fn = "shdr_bn_bwd_f16" if h else "shdr_bn_bwd_f32"
+    _lib.check(getattr(lib, fn)(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
+                                _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _stream()), fn)
     return dx, dgamma, dbeta
 
 
@@ -747,6 +824,12 @@ def blend_const(base, alpha, hal_bgr, thr=0.12):
 
 def vgg_preprocess_bwd(dy):
     lib = _lib.load()
+    if _is_h(dy):
+        dy = _chkh(_d(dy), "dy")
+        dx = torch.empty(tuple(dy.shape[:-1]) + (3,), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.shdr_unpack3_f16(_ptr(dy), _ptr(dx), None, None, None, 1, dy.shape[-1], dy.numel() // dy.shape[-1], 1, _stream()),
+                   "shdr_unpack3_f16")
+        return dx
     dy = _chk(_d(dy), "dy")
     ic = dy.shape[-1]
     npix = dy.numel() // ic
@@ -777,10 +860,12 @@ def _mutated(*tensors):
 
 def lin_frontend_bwd(img, dF):
     lib = _lib.load()
-    img, dF = _chk(_d(img), "img"), _chk(_d(dF), "dF")
+    h16 = _is_h(dF)
+    img, dF = _chk(_d(img), "img"), (_chkh(_d(dF), "dF") if h16 else _chk(_d(dF), "dF"))
     n, h, w, _ = img.shape
     dimg = torch.empty_like(img)
-    _lib.check(lib.shdr_lin_frontend_bwd_f32(_ptr(img), _ptr(dF), _ptr(dimg), n, h, w, dF.shape[3], _stream()), "shdr_lin_frontend_bwd_f32")
+    fn = "shdr_lin_frontend_bwd_f16" if h16 else "shdr_lin_frontend_bwd_f32"
+    _lib.check(getattr(lib, fn)(_ptr(img), _ptr(dF), _ptr(dimg), n, h, w, dF.shape[3], _stream()), fn)
     return dimg
 
 
@@ -799,11 +884,15 @@ def unpack3(y, nout):
     if _needs_grad(y):
         return AUTOGRAD.unpack3(y, nout)
     lib = _lib.load()
-    y = _chk(_d(y), "y")
+    h16 = _is_h(y)
+    y = _chkh(_d(y), "y") if h16 else _chk(_d(y), "y")
     c = y.shape[-1]
     npix = y.numel() // c
     outs = [torch.empty(tuple(y.shape[:-1]) + (3,), device=y.device, dtype=torch.float32) for _ in range(nout)]
     p = [_ptr(o) for o in outs] + [None] * (4 - nout)
+    if h16:
+        _lib.check(lib.shdr_unpack3_f16(_ptr(y), p[0], p[1], p[2], p[3], nout, c, npix, 0, _stream()), "shdr_unpack3_f16")
+        return tuple(outs)
     _lib.check(lib.shdr_unpack3_f32(_ptr(y), p[0], p[1], p[2], p[3], nout, c, npix, _stream()), "shdr_unpack3_f32")
     return tuple(outs)
 
@@ -843,6 +932,136 @@ def mean_norm_bwd(g, ssum, gdot, eps, target):
     _lib.check(lib.shdr_mean_norm_bwd_f32(_ptr(g), _ptr(ssum), _ptr(gdot), _ptr(dr), bs, g.numel() // bs, float(eps), float(target),
                                           _stream()), "shdr_mean_norm_bwd_f32")
     return dr
+
+
+# ---------------------------------------------------------------------------
+# native-fp16 path of BASELINE configs[4] (csrc/conv_f16.hip, wgrad_f16.hip, elem_f16.hip)
+# ---------------------------------------------------------------------------
+def to_half(x):
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    y = torch.empty(x.shape, device=x.device, dtype=HALF)
+    _lib.check(lib.shdr_cast_f32_to_f16(_ptr(x), _ptr(y), x.numel(), _stream()), "shdr_cast_f32_to_f16")
+    return y
+
+
+def to_float(x):
+    lib = _lib.load()
+    x = _chk(_d(x), "x", HALF)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_cast_f16_to_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "shdr_cast_f16_to_f32")
+    return y
+
+
+def pad_channels_h(x, channels):
+    """fp32 [..., c] -> fp16 [..., channels] zero-padded (the gradient of a 3-channel head onto an 8-channel group)"""
+    lib = _lib.load()
+    x = _chk(_d(x), "x")
+    c = x.shape[-1]
+    y = torch.empty(tuple(x.shape[:-1]) + (channels,), device=x.device, dtype=HALF)
+    _lib.check(lib.shdr_pad_channels_f32_to_f16(_ptr(x), _ptr(y), x.numel() // c, c, channels, _stream()), "shdr_pad_channels_f32_to_f16")
+    return y
+
+
+def pack_filter_h(w, c1, c2=0, x2_scale=1.0):
+    """fp32 HWIO filter -> the packed fp16 filter of conv2d_h ([k-chunk][Cout][32]; x2_scale folded into the x2 rows); kept ON
+    the filter tensor per version for persistent variables, like the packed Winograd filters"""
+    key = None
+    if (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False):
+        key = (w._version, c1, c2, float(x2_scale))
+        cached = getattr(w, "_shdr_packed_h", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+    lib = _lib.load()
+    wd = _chk(_d(w), "w")
+    kh, kw, cin, cout = wd.shape
+    if cin != c1 + c2:
+        raise ValueError("pack_filter_h: filter has %d input channels, sources have %d+%d" % (cin, c1, c2))
+    n = int(lib.shdr_conv2d_packed_filter_elems_f16(kh, kw, c1, c2, cout))
+    wp = torch.empty(n, device=wd.device, dtype=HALF)
+    _lib.check(lib.shdr_conv2d_pack_filter_f16(_ptr(wd), _ptr(wp), kh, kw, c1, c2, cout, float(x2_scale), _stream()),
+               "shdr_conv2d_pack_filter_f16")
+    if key is not None:
+        w._shdr_packed_h = (key, wp)
+    return wp
+
+
+def _conv_desc_h(x_shape, c2, khw, cout_gemm, stride, cout_valid, pad=None, out_hw=None):
+    n, h, wd, c1 = x_shape
+    kh, kw = khw
+    ho, pt = same_pad(h, kh, stride)
+    wo, pl = same_pad(wd, kw, stride)
+    if pad is not None:
+        pt, pl = pad
+    if out_hw is not None:
+        ho, wo = out_hw
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
+    d.Cout, d.KH, d.KW, d.stride = cout_gemm, kh, kw, stride
+    d.cout_valid = cout_valid or cout_gemm
+    d.pad_t, d.pad_l, d.Ho, d.Wo = pt, pl, ho, wo
+    d.x2_scale = 1.0
+    return d
+
+
+def conv2d_h(x, wp, bias, khw, cout_gemm, stride=1, x2=None, act1=ACT_NONE, cout_valid=None, pad=None, out_hw=None):
+    """y = act1(conv(concat[x, x2], wp) + bias) on fp16 feature maps, `wp` from pack_filter_h.  The output is fp16
+    [N,Ho,Wo,cout_gemm], or fp32 [N,Ho,Wo,cout_valid] for a narrow head (cout_valid < cout_gemm: image-like tensors stay fp32)."""
+    lib = _lib.load()
+    x = _chkh(_d(x), "x")
+    c2 = 0
+    if x2 is not None:
+        x2 = _chkh(_d(x2), "x2")
+        if x2.shape[:3] != x.shape[:3]:
+            raise ValueError("conv2d_h: x2 spatial shape %s != x %s" % (tuple(x2.shape), tuple(x.shape)))
+        c2 = x2.shape[3]
+    head = cout_valid is not None and cout_valid < cout_gemm
+    d = _conv_desc_h(x.shape, c2, khw, cout_gemm, stride, cout_valid if head else None, pad, out_hw)
+    d.act1 = act1
+    if bias is not None and _chk(_d(bias), "bias").numel() < (cout_valid if head else cout_gemm):
+        raise ValueError("conv2d_h: bias too short")
+    y = torch.empty((x.shape[0], d.Ho, d.Wo, cout_valid if head else cout_gemm), device=x.device, dtype=torch.float32 if head else HALF)
+    _lib.check(lib.shdr_conv2d_fwd_f16(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(wp), _ptr(_d(bias)), _ptr(y), int(head), _stream()),
+               "shdr_conv2d_fwd_f16")
+    return y
+
+
+def conv2d_wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None):
+    """dW [kh,kw,C1+C2,Cout] (fp32) of conv(concat[x, x2_scale*x2], W) from fp16 x / x2 / dz; columns >= cout_valid stay zero"""
+    lib = _lib.load()
+    kh, kw, cin, cout = w_shape
+    x, dz = _chkh(_d(x), "x"), _chkh(_d(dz), "dz")
+    c1 = x.shape[3]
+    c2 = 0 if x2 is None else x2.shape[3]
+    if cin != c1 + c2:
+        raise ValueError("conv2d_wgrad_h: filter %s does not match the sources (%d+%d channels)" % (tuple(w_shape), c1, c2))
+    d = _conv_desc_h(x.shape, c2, (kh, kw), cout, stride, cout_valid)
+    d.x2_scale = float(x2_scale)
+    if tuple(dz.shape[:3]) != (x.shape[0], d.Ho, d.Wo):
+        raise ValueError("conv2d_wgrad_h: dz spatial shape mismatch")
+    dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+    _lib.check(lib.shdr_conv2d_wgrad_f16(ctypes.byref(d), _ptr(x), 0, _ptr(dz), dz.shape[3], c1, c2, _ptr(dw), _stream()),
+               "shdr_conv2d_wgrad_f16")
+    if x2 is not None:
+        _lib.check(lib.shdr_conv2d_wgrad_f16(ctypes.byref(d), _ptr(_chkh(_d(x2), "x2")), 1, _ptr(dz), dz.shape[3], c1, c2, _ptr(dw),
+                                             _stream()), "shdr_conv2d_wgrad_f16")
+    return dw
+
+
+def act_bwd_bias_h(dy, y, act, want_db):
+    """(dz, db) on fp16 tensors: dz = dy * act'(y) (dy itself when act is NONE), db = sum over pixels of dz in fp32 (or None)"""
+    lib = _lib.load()
+    dy = _chkh(_d(dy), "dy")
+    c = dy.shape[-1]
+    db = torch.zeros(c, device=dy.device, dtype=torch.float32) if want_db else None
+    if act == ACT_NONE:
+        if want_db:
+            _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), None, None, _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f16")
+        return dy, db
+    y = _chkh(_d(y), "y")
+    dz = torch.empty_like(dy)
+    _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f16")
+    return dz, db
 
 
 # ---------------------------------------------------------------------------

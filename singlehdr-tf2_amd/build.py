@@ -20,6 +20,9 @@ LIB = os.path.join(HERE, "libshdr.so")
 SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
+    "conv_f16.hip": [],
+    "wgrad_f16.hip": [],
+    "elem_f16.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
     "wgrad_winograd.hip": [],
     "bwd.hip": [],

@@ -62,7 +62,9 @@ class _unet(Layer):
 
     def _trunk(self, input_images):
         cin = input_images.shape[-1]
-        if cin == 3:      # 3 -> 4 channels (zero) so that the 7x7 conv runs on the MFMA tile
+        if cin == 3 and K.native_fp16():     # BASELINE configs[4]: fp16 feature maps from here on (3 -> 8 channels = one 16-byte group)
+            x = self.conv1.call_padded(K.pack3([input_images], 8, K.HALF), cin_pad=8, act1=K.ACT_LRELU)
+        elif cin == 3:    # 3 -> 4 channels (zero) so that the 7x7 conv runs on the MFMA tile
             x = self.conv1.call_padded(K.pack3([input_images], 4), cin_pad=4, act1=K.ACT_LRELU)
         elif cin % 4 == 0 and cin != self.conv1.kernel.shape[2]:   # caller passed a zero-padded input
             x = self.conv1.call_padded(input_images, cin_pad=cin, act1=K.ACT_LRELU)

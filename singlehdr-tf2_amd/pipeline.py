@@ -352,9 +352,9 @@ class FinetuneStep:
 
     def __init__(self, deq, lin, hal, ref, lr=None, process_group=None, world_size=1, precision="fp32",
                  loss_scale=1.0):
-        """precision: MFMA operand precision of every conv forward / dgrad / wgrad of the step -- "fp32" (parity
-        path) or "fp16" / "bf16" (BASELINE configs[4]: fp32 master weights, fp32 activations in HBM, fp32
-        accumulation; operands rounded inside the kernels).  loss_scale: static scale applied to the seed gradient
+        """precision: "fp32" (parity path); "fp16" = BASELINE configs[4], the NATIVE fp16 conv path: fp16 feature maps in HBM
+        for every conv forward / dgrad / wgrad, BatchNorm, pooling and resize pass, fp32 master weights, fp32 parameter gradients
+        and fp32 accumulation (_ops.PRECISION); "fp16op" / "bf16" = the round-1 operand-rounding modes (fp32 tensors in HBM).  loss_scale: static scale applied to the seed gradient
         and divided out of the flat gradient before the collective.  The loss here is a SUM over pixels, so output
         gradients are O(1)..O(1e3) and need no up-scaling; 256 overflows fp16 at 512x512 tiles (measured)."""
         self._deq, self._lin, self._hal, self._ref = deq, lin, hal, ref
@@ -373,7 +373,10 @@ class FinetuneStep:
         A_pred = K.alpha_blend(B_pred, bgr_hal_res, self.THRESHOLD)      # alpha is a function of B_pred here
         with torch.no_grad():
             hdr_gamma = K.logc(hdr)
-        refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 12), training=True)
+        if self.precision == "fp16":                 # fp16 feature maps: [A, B, C, 0...] on two 16-byte channel groups
+            refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 16, K.HALF), training=True)
+        else:
+            refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 12), training=True)
         refinement_output = K.mean_norm(refinement_output, 1e-6, 0.5)
         refinement_output_gamma = K.logc(refinement_output)
         n_per = refinement_output_gamma[0].numel()
@@ -390,7 +393,7 @@ class FinetuneStep:
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)
-        if self.precision == "fp16" and not bool(torch.isfinite(self.params.grad.sum())):
+        if self.precision in ("fp16", "fp16op") and not bool(torch.isfinite(self.params.grad.sum())):
             # an fp16 operand overflowed (|value| > 65504).  Checked after the collective, so every rank sees it: drop
             # the step like a dynamic loss scaler would.  The batch-summed loss makes output gradients GROW with the
             # tile size, so the remedy is loss_scale < 1.

@@ -1,4 +1,5 @@
-"""GPU tests of the reduced-precision MFMA operand path (BASELINE configs[4]: "fp16 MFMA conv path").
+"""GPU tests of the round-1 reduced-precision OPERAND modes ("fp16op" / "bf16"; the native-fp16 path of BASELINE configs[4] is
+tested against the float64 oracle in tests/test_gpu_fp16_oracle.py).
 
 Tensors stay fp32 in HBM; the conv forward / dgrad / wgrad kernels round activations, filters and output
 gradients to fp16 (bf16) when they pack the operands of v_mfma_f32_16x16x32_{f16,bf16} and accumulate in fp32.
@@ -15,7 +16,7 @@ from conftest import quantised_image
 from oracle import nets
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp16": 2e-3, "bf16": 2e-2}
+TOL = {"fp16op": 2e-3, "bf16": 2e-2}
 
 
 def maxrel(a, b):
@@ -33,7 +34,7 @@ SHAPES = [  # n, h, w, c1, c2, cout, k, stride
 ]
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16op", "bf16"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv_forward_reduced_precision(shdr, prec, shape):
     K = shdr._ops
@@ -49,7 +50,7 @@ def test_conv_forward_reduced_precision(shdr, prec, shape):
         with K.precision(prec):
             got = K.conv2d(x, wt, b, stride=s, x2=x2, act1=K.ACT_LRELU)
         forced = K.conv2d(x, wt, b, stride=s, x2=x2, act1=K.ACT_LRELU,
-                          algo=K.ALGO_MFMA_F16 if prec == "fp16" else K.ALGO_MFMA_BF16)
+                          algo=K.ALGO_MFMA_F16 if prec == "fp16op" else K.ALGO_MFMA_BF16)
     finally:
         K.WINOGRAD = saved
     err = maxrel(forced, ref)
@@ -82,12 +83,12 @@ def test_reduced_precision_needs_folded_x2_scale(shdr):
     with pytest.raises(RuntimeError, match="x2_scale"):
         K.conv2d(x, w, x2=x, x2_scale=0.5, algo=K.ALGO_MFMA_F16)
     # AUTO_F16 keeps such a layer on the fp32 kernels instead
-    with K.precision("fp16"):
+    with K.precision("fp16op"):
         y = K.conv2d(x, w, x2=x, x2_scale=0.5)
     assert torch.equal(y, K.conv2d(x, w, x2=x, x2_scale=0.5))
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16op", "bf16"])
 def test_conv_backward_reduced_precision(shdr, prec):
     """dgrad and wgrad (MFMA over pixels) with reduced-precision operands vs the exact-fp32 kernels."""
     K = shdr._ops
@@ -125,7 +126,7 @@ def steps(shdr):
     hdr = hdr / (1e-6 + hdr.mean(axis=(1, 2, 3), keepdims=True)) * 0.5
     mods = dict(deq="dequantization_net", lin="linearization_net", hal="hallucination_net", ref="refinement_net")
     out = {}
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16op", "bf16"):
         ms = {k: getattr(shdr, mods[k]).model().load_numpy(P[k]) for k in mods}
         out[prec] = (shdr.pipeline.FinetuneStep(ms["deq"], ms["lin"], ms["hal"], ms["ref"], lr=1e-4, precision=prec,
                                                 loss_scale=1.0 if prec == "fp32" else 0.25), ms)
@@ -133,12 +134,12 @@ def steps(shdr):
     return out, t(ldr), t(hdr)
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16op", "bf16"])
 def test_finetune_step_reduced_precision_tracks_fp32(steps, prec):
     out, ldr, hdr = steps
     ref = out["fp32"][0](ldr, hdr, apply=False)
     got = out[prec][0](ldr, hdr, apply=False)
-    scale = 1.0 if prec == "fp16" else 16.0      # bf16 keeps 8 mantissa bits: ~8x the fp16 round-off per layer
+    scale = 1.0 if prec == "fp16op" else 16.0      # bf16 keeps 8 mantissa bits: ~8x the fp16 round-off per layer
     for k in ("C_pred", "B_pred", "A_pred", "refinement_output"):
         assert maxrel(got[k], ref[k]) <= 2e-2 * scale, k     # 0.6-1.2e-2 observed, depending on which layers run exact
     assert maxrel(got["loss_sum"], ref["loss_sum"]) <= 1e-2 * scale
@@ -148,12 +149,12 @@ def test_finetune_step_reduced_precision_tracks_fp32(steps, prec):
     # perturbation (relu / max-pool masks flip, test_gpu_grad.py); operand rounding is a 5e-4 (4e-3) perturbation of
     # every layer, so the bar here is the DIRECTION of the flat 29 M-element gradient, and that the step still descends
     cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
-    assert cos >= (0.97 if prec == "fp16" else 0.85), cos
+    assert cos >= (0.97 if prec == "fp16op" else 0.85), cos
 
 
 def test_finetune_fp16_reduces_the_loss(steps):
     out, ldr, hdr = steps
-    step = out["fp16"][0]
+    step = out["fp16op"][0]
     first = float(step(ldr, hdr)["loss_sum"].detach().sum())
     for _ in range(4):
         last = float(step(ldr, hdr)["loss_sum"].detach().sum())
@@ -163,7 +164,7 @@ def test_finetune_fp16_reduces_the_loss(steps):
 def test_fp16_overflow_skips_the_step(steps):
     """An absurd loss scale overflows the fp16 output-gradient operands: the step is dropped, weights untouched."""
     out, ldr, hdr = steps
-    step = out["fp16"][0]
+    step = out["fp16op"][0]
     before = step.params.flat.clone()
     saved, step.loss_scale = step.loss_scale, 1e9
     try:

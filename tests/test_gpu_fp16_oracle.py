@@ -43,6 +43,9 @@ CASES = [
     ("res_1x1_64_256", 1, 20, 20, 64, 0, 256, 1, 1, 0, 1.0),
     ("wide_3x3_512_512", 1, 8, 8, 512, 0, 512, 3, 1, 1, 1.0),
     ("ragged_3x3_16_16", 2, 13, 19, 16, 0, 16, 3, 1, 2, 1.0),
+    ("concat_16_16_16_lrelu", 1, 20, 36, 16, 16, 16, 3, 1, 2, 1.0),          # natural k order with two sources (deq / ref u1)
+    ("stem_7x7_8_16_lrelu", 1, 24, 24, 8, 0, 16, 7, 1, 2, 1.0),              # 3 -> 8 channel image input, K tail 392 = 12.25 chunks
+    ("wide_pixels_3x3_32_32", 4, 72, 80, 32, 0, 32, 3, 1, 1, 1.0),          # several pixel slices per weight-gradient tile
 ]
 
 
@@ -67,13 +70,15 @@ def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case):
     np.testing.assert_allclose(z.detach().numpy(), ops.conv2d(np_in, wt.astype(np.float64), b.astype(np.float64), stride),
                                rtol=1e-9, atol=1e-9)
     (y * R.T(gy)).sum().backward()
-    # HIP, fp16 MFMA conv path
-    dx, dw, db = dev(x, True), dev(wt, True), dev(b, True)
-    dx2 = dev(x2, True) if c2 else None
+    # HIP, native-fp16 conv path: fp16 feature maps in and out, fp32 filter / bias and fp32 parameter gradients
+    dx, dw, db = dev(x).half().requires_grad_(True), dev(wt, True), dev(b, True)
+    dx2 = dev(x2).half().requires_grad_(True) if c2 else None
     with K.precision("fp16"):
         yy = K.conv2d(dx, dw, db, stride=stride, x2=dx2, x2_scale=x2s, act1=act)
+        assert yy.dtype == torch.float16 and dw.dtype == torch.float32
         assert rel_err(host(yy), y.detach().numpy()) <= LAYER_TOL
         (yy.float() * dev(gy)).sum().backward()
+    assert dx.grad.dtype == torch.float16 and dw.grad.dtype == torch.float32
     assert rel_err(host(dx.grad), tx.grad.numpy()) <= LAYER_TOL, "dx"
     if c2:
         assert rel_err(host(dx2.grad), tx2.grad.numpy()) <= LAYER_TOL, "dx2"
@@ -108,8 +113,6 @@ def test_fp16_finetune_step_vs_float64_oracle(ft16, emor_table):
     # gradients: float64 autograd reference (tests/torch_ref.py, pinned to the NumPy oracle at 1e-9)
     got = ft16["step"].params.grad.double().cpu().numpy()
     ref = np.zeros_like(got)
-    for v, o in zip(ft16["step"].params.variables, ft16["step"].params.offsets):
-        pass
     names = [(net, n) for net in ("deq", "lin", "hal", "ref") for n, _, tr in ft16["ms"][net].named_weights() if tr]
     for (net, n), o in zip(names, ft16["step"].params.offsets):
         g = ft16["tP"][net][n].grad.numpy().ravel()
@@ -146,3 +149,112 @@ def test_fp16_finetune_1024_tiles_properties(shdr):
     assert step.skipped_steps == 0
     assert np.isfinite(last) and last < first, (first, last)
     assert tuple(o1["refinement_output"].shape) == (b, sz, sz, 3)
+
+
+def test_fp16_head_conv_returns_fp32_three_channels(shdr):
+    """the zero-padded 3-channel heads (dequantization_net.py:46, hallucination_net.py:183): fp16 in, fp32 [.., 3] out,
+    gradients back onto fp16"""
+    K = shdr._ops
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=(2, 12, 20, 16)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, 16, 3)) / 12.0).astype(np.float32)
+    b = (rng.normal(size=3) * 0.1).astype(np.float32)
+    gy = rng.normal(size=(2, 12, 20, 3)).astype(np.float32)
+    tx, tw, tb = R.T(x, True), R.T(wt, True), R.T(b, True)
+    y = torch.tanh(R.conv2d(tx, tw, tb, 1))
+    (y * R.T(gy)).sum().backward()
+    dx, dw, db = dev(x).half().requires_grad_(True), dev(wt, True), dev(b, True)
+    wpad = torch.nn.functional.pad(dw, (0, 13))                      # what Conv2D.call_padded does on the tape
+    with K.precision("fp16"):
+        yy = K.conv2d(dx, wpad, db, act1=K.ACT_TANH, cout_valid=3)
+    assert yy.dtype == torch.float32 and tuple(yy.shape) == (2, 12, 20, 3)
+    assert rel_err(host(yy), y.detach().numpy()) <= LAYER_TOL
+    (yy * dev(gy)).sum().backward()
+    assert rel_err(host(dx.grad), tx.grad.numpy()) <= LAYER_TOL
+    assert rel_err(host(dw.grad), tw.grad.numpy()) <= LAYER_TOL
+    assert rel_err(host(db.grad), tb.grad.numpy()) <= LAYER_TOL
+
+
+def test_fp16_elementwise_twins_vs_oracle(shdr, emor_table):
+    """pooling / resize / BatchNorm / residual joins / front end on fp16 feature maps against the float64 oracle evaluated on the
+    SAME (fp16-representable) inputs: the only error left is the rounding of the stored result (u = 4.9e-4) and fp32 arithmetic"""
+    K = shdr._ops
+    rng = np.random.default_rng(3)
+    TOLE = 1.5e-3
+    x = rng.normal(size=(2, 12, 20, 24)).astype(np.float16)
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    x64 = x.astype(np.float64)
+    tx = R.T(x64, True)
+    gy_small = rng.normal(size=(2, 6, 10, 24)).astype(np.float16)
+    for name, fn, tfn in (("avgpool2", K.avgpool2, R.avg_pool2), ("maxpool2", K.maxpool2, lambda t: R.max_pool(t, 2, 2)),
+                          ("maxpool3s2", K.maxpool3s2, lambda t: R.max_pool(t, 3, 2))):
+        tx.grad = None
+        xd.grad = None
+        ty = tfn(tx)
+        (ty * R.T(gy_small.astype(np.float64))).sum().backward()
+        yy = fn(xd)
+        assert yy.dtype == torch.float16 and rel_err(host(yy), ty.detach().numpy()) <= TOLE, name
+        (yy.float() * torch.from_numpy(gy_small).cuda().float()).sum().backward()
+        assert rel_err(host(xd.grad), tx.grad.numpy()) <= TOLE, name + " bwd"
+    gy_big = rng.normal(size=(2, 24, 40, 24)).astype(np.float16)
+    tx.grad = None
+    xd.grad = None
+    ty = R.resize2x(tx)
+    np.testing.assert_allclose(ty.detach().numpy(), ops.resize_bilinear_2x(x64), atol=1e-12)
+    (ty * R.T(gy_big.astype(np.float64))).sum().backward()
+    yy = K.resize2x(xd)
+    assert rel_err(host(yy), ty.detach().numpy()) <= TOLE
+    (yy.float() * torch.from_numpy(gy_big).cuda().float()).sum().backward()
+    assert rel_err(host(xd.grad), tx.grad.numpy()) <= TOLE
+    # global average pool: fp32 out, fp16 gradient
+    tx.grad = None
+    xd.grad = None
+    g2 = rng.normal(size=(2, 24)).astype(np.float32)
+    (tx.mean(dim=(1, 2)) * R.T(g2)).sum().backward()
+    yy = K.global_avg_pool(xd)
+    assert yy.dtype == torch.float32 and rel_err(host(yy), x64.mean(axis=(1, 2))) <= 1e-5
+    (yy * torch.from_numpy(g2).cuda()).sum().backward()
+    assert xd.grad.dtype == torch.float16 and rel_err(host(xd.grad), tx.grad.numpy()) <= TOLE
+    # training-mode BatchNorm (+ relu), statistics in double
+    L = __import__("importlib").import_module("singlehdr-tf2_amd._layers")
+    bn = L.BatchNormalization(24)
+    with torch.no_grad():
+        bn.gamma.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 24).astype(np.float32)))
+        bn.beta.copy_(torch.from_numpy(rng.normal(0, 0.1, 24).astype(np.float32)))
+    p = {"n.gamma": R.T(host(bn.gamma).astype(np.float64), True), "n.beta": R.T(host(bn.beta).astype(np.float64), True)}
+    gyb = rng.normal(size=x.shape).astype(np.float16)
+    tx.grad = None
+    xd.grad = None
+    ty = torch.relu(R.bn(p, "n", tx, True))
+    (ty * R.T(gyb.astype(np.float64))).sum().backward()
+    yy = bn.train_apply(xd, relu=True)
+    assert yy.dtype == torch.float16 and rel_err(host(yy), ty.detach().numpy()) <= TOLE
+    (yy.float() * torch.from_numpy(gyb).cuda().float()).sum().backward()
+    assert rel_err(host(xd.grad), tx.grad.numpy()) <= 3e-3
+    assert rel_err(host(bn.gamma.grad), p["n.gamma"].grad.numpy()) <= 3e-3
+    assert rel_err(host(bn.beta.grad), p["n.beta"].grad.numpy()) <= 3e-3
+    mm = x64.mean(axis=(0, 1, 2)) * 0.01
+    assert rel_err(host(bn.moving_mean), mm) <= 1e-4                      # Keras momentum 0.99 from zero
+    # residual joins
+    a, b = rng.normal(size=(2, 5, 7, 16)).astype(np.float16), rng.normal(size=(2, 5, 7, 16)).astype(np.float16)
+    ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    assert rel_err(host(K.add(ad, bd)), a.astype(np.float64) + b.astype(np.float64)) <= TOLE
+    assert rel_err(host(K.add(ad, bd, relu=True)), np.maximum(a.astype(np.float64) + b.astype(np.float64), 0)) <= TOLE
+    # Linearization-Net front end: fp32 image -> fp16 [.., 96]; histogram channels are exact in fp16 for quantised inputs only
+    img = quantised_image(rng, (2, 16, 20, 3))
+    with K.precision("fp16"):
+        f = K.lin_frontend(dev(img), 96)
+    assert f.dtype == torch.float16
+    want = ops.lin_frontend(img) if hasattr(ops, "lin_frontend") else None
+    ti = R.T(img, True)
+    tf = R.lin_frontend(ti) if hasattr(R, "lin_frontend") else None
+    if tf is not None:
+        assert rel_err(host(f)[..., :93], tf.detach().numpy()) <= TOLE
+        gf = rng.normal(size=(2, 16, 20, 96)).astype(np.float16)
+        (tf * R.T(gf[..., :93].astype(np.float64))).sum().backward()
+        di = dev(img, True)
+        with K.precision("fp16"):
+            ff = K.lin_frontend(di, 96)
+        (ff.float() * torch.from_numpy(gf).cuda().float()).sum().backward()
+        assert rel_err(host(di.grad), ti.grad.numpy()) <= 2e-3
+    assert float(host(f)[..., 93:].max()) == 0.0

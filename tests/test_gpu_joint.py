@@ -58,7 +58,7 @@ def test_joint_losses_match_reference(setup):
     for k in ("loss_deq", "loss_lin", "loss_hal", "total", "crf_loss"):
         want = setup["ref"][k].detach().numpy()
         assert rel_err(host(out[k]).reshape(want.shape), want) <= 1e-4, k
-    assert float(out["total"][-1].abs().max()) == 0.0           # row of the masked sample: nothing but TV * 0
+    assert float(out["total"][-1].detach().abs().max()) == 0.0           # row of the masked sample: nothing but TV * 0
     # what is differentiated is the sum over the [b,1,b,1] tensor
     assert abs(float(out["objective"]) - float(out["total"].sum())) <= 1e-5 * abs(float(out["total"].sum()))
     for k in ("C_pred", "B_pred", "A_pred"):
