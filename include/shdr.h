@@ -370,6 +370,14 @@ int shdr_conv2d_fwd_f16(const shdr_conv2d_desc* d, const void* x1, const void* x
  * dz fp16 with dz_channels per pixel; dw = [KH,KW,c1_rows + c2_rows, d->Cout], of which the first cout_valid columns are written. */
 int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels, int c1_rows,
                           int c2_rows, float* dw, void* stream);
+/* specialised forms the two entry points above dispatch to (exported so that a host can test / force them): the narrow-layer
+ * forward with the raw patch and the whole filter resident in LDS, and the all-taps weight gradient of stride-1 layers */
+int shdr_conv2d_patch_ok_f16(const shdr_conv2d_desc* d);
+int shdr_conv2d_fwd_patch_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias, void* y,
+                              int y_is_f32, void* stream);
+int shdr_conv2d_wgrad_alltaps_ok_f16(const shdr_conv2d_desc* d, int which, int dz_channels);
+int shdr_conv2d_wgrad_alltaps_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels, int c1_rows,
+                                  int c2_rows, float* dw, void* stream);
 int shdr_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 int shdr_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
 /* fp32 [npix, Cin] -> fp16 [npix, Cout] zero-padded (narrow gradients of the 3-channel heads onto 8-channel groups) */

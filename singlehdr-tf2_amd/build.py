@@ -21,7 +21,9 @@ SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
     "conv_f16.hip": [],
+    "conv_f16_patch.hip": [],
     "wgrad_f16.hip": [],
+    "wgrad_f16_alltaps.hip": [],
     "elem_f16.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
     "wgrad_winograd.hip": [],

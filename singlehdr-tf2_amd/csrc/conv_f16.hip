@@ -333,6 +333,10 @@ int launch_f16_k(ConvHArgs& a, hipStream_t st) {
   return a.nchunks >= 2 ? launch_f16<BM, BN, WM, WN, false, 2>(a, st) : launch_f16<BM, BN, WM, WN, false, 1>(a, st);
 }
 
+extern "C" int shdr_conv2d_patch_ok_f16(const shdr_conv2d_desc* d);
+extern "C" int shdr_conv2d_fwd_patch_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias,
+                                         void* y, int y_is_f32, void* stream);
+
 inline bool f16_fast(int C1, int C2) { return ((C1 + C2) % 32 == 0) && (C2 == 0 || C1 % 32 == 0); }
 inline int f16_nchunks(int ntaps, int C1, int C2) {
   const int Ct = C1 + C2;
@@ -397,6 +401,9 @@ extern "C" int shdr_conv2d_fwd_f16(const shdr_conv2d_desc* d, const void* x1, co
   a.act1 = d->act1;
   a.cout_valid = cout_valid;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // narrow full-resolution layers (<= 32 channels per tap, 16 / 32 couts): raw patch + resident filter in LDS (conv_f16_patch.hip)
+  if (shdr_conv2d_patch_ok_f16(d) && getenv("SHDR_NO_PATCH") == nullptr)
+    return shdr_conv2d_fwd_patch_f16(d, x1, x2, wp, bias, y, y_is_f32, stream);
   if (a.Cout % 128 == 0) return launch_f16_k<128, 128, 2, 2>(a, st);
   if (a.Cout % 64 == 0) return launch_f16_k<256, 64, 4, 1>(a, st);
   if (a.Cout % 32 == 0) return launch_f16_k<256, 32, 4, 1>(a, st);

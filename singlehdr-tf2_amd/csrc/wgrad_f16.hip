@@ -261,6 +261,10 @@ int dispatch_co(WgradHArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int shdr_conv2d_wgrad_alltaps_ok_f16(const shdr_conv2d_desc* d, int which, int dz_channels);
+extern "C" int shdr_conv2d_wgrad_alltaps_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels,
+                                             int c1_rows, int c2_rows, float* dw, void* stream);
+
 extern "C" int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels, int c1_rows,
                                      int c2_rows, float* dw, void* stream) {
   SHDR_REQUIRE(d && x && dz && dw, SHDR_E_NULL, "wgrad_f16: null pointer");
@@ -277,6 +281,9 @@ extern "C" int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, i
   SHDR_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31) && (long)d->N * d->H * d->W * Cx < (1L << 32), SHDR_E_SHAPE,
                "wgrad_f16: tensor too large");
   SHDR_REQUIRE(shdr::aligned16(x) && shdr::aligned16(dz), SHDR_E_ALIGN, "wgrad_f16: tensors must be 16-byte aligned");
+  // stride-1 layers with many pixels: every tap from one staged strip (wgrad_f16_alltaps.hip)
+  if (shdr_conv2d_wgrad_alltaps_ok_f16(d, which, dz_channels) && getenv("SHDR_NO_ALLTAPS") == nullptr)
+    return shdr_conv2d_wgrad_alltaps_f16(d, x, which, dz, dz_channels, c1_rows, c2_rows, dw, stream);
   WgradHArgs a{};
   a.x = reinterpret_cast<const _Float16*>(x);
   a.dz = reinterpret_cast<const _Float16*>(dz);

@@ -46,12 +46,27 @@ CASES = [
     ("concat_16_16_16_lrelu", 1, 20, 36, 16, 16, 16, 3, 1, 2, 1.0),          # natural k order with two sources (deq / ref u1)
     ("stem_7x7_8_16_lrelu", 1, 24, 24, 8, 0, 16, 7, 1, 2, 1.0),              # 3 -> 8 channel image input, K tail 392 = 12.25 chunks
     ("wide_pixels_3x3_32_32", 4, 72, 80, 32, 0, 32, 3, 1, 1, 1.0),          # several pixel slices per weight-gradient tile
+    ("alltaps_3x3_64_64_mode1", 2, 40, 72, 64, 0, 64, 3, 1, 1, 1.0),          # 2 x 2 wave split, all taps per wave
+    ("alltaps_3x3_128_64_two_ci_tiles", 1, 33, 50, 128, 0, 64, 3, 1, 0, 1.0),
+    ("unet_5x5_32_32_lrelu", 2, 21, 40, 32, 0, 32, 5, 1, 2, 1.0),
+    ("unet_3x3_32_16_lrelu", 2, 19, 35, 32, 0, 16, 3, 1, 2, 1.0),
+    ("unet_3x3_16_32", 1, 32, 32, 16, 0, 32, 3, 1, 0, 1.0),
+    ("unet_3x3_64_32_lrelu", 1, 24, 40, 64, 0, 32, 3, 1, 2, 1.0),
 ]
 
 
+@pytest.mark.parametrize("kernels", ["specialised", "general"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case):
+def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case, kernels, monkeypatch):
+    """`specialised`: the narrow layers take the patch kernel (conv_f16_patch.hip) and every eligible stride-1 layer the all-taps
+    weight gradient (wgrad_f16_alltaps.hip; its many-pixels threshold is lifted so that these small shapes reach it);
+    `general`: the implicit-GEMM kernel and the per-tap weight gradient for every shape."""
     name, n, h, w, c1, c2, cout, k, stride, act, x2s = case
+    if kernels == "specialised":
+        monkeypatch.setenv("SHDR_ALLTAPS_MIN_PIXELS", "0")
+    else:
+        monkeypatch.setenv("SHDR_NO_PATCH", "1")
+        monkeypatch.setenv("SHDR_NO_ALLTAPS", "1")
     K = shdr._ops
     rng = np.random.default_rng(len(name) * 17 + h)
     x = rng.normal(size=(n, h, w, c1)).astype(np.float32)
