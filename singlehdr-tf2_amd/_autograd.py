@@ -22,6 +22,18 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _acc(p):
+    """The gradient buffer of a variable that a training step has placed in its flat gradient buffer (pipeline.FlatParams
+    marks them): the backward kernels ACCUMULATE into it directly (they add with atomics anyway) and the tape entry returns no
+    gradient for it -- no zero-filled temporary and no separate accumulation pass per variable."""
+    if p is None or not getattr(p, "_shdr_accum", False) or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 # ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------
@@ -90,6 +102,7 @@ class Conv2dFn(torch.autograd.Function):
                      cout_valid=cout_valid)
         ctx.save_for_backward(x, x2, w, y)
         ctx.meta = (stride, x2_scale, act1, bias is not None)
+        ctx.bias_ref = bias             # (not a saved tensor: only its .grad buffer is looked up in backward)
         ctx.prec = K.PRECISION          # the backward kernels run at the precision of the forward
         return y
 
@@ -106,14 +119,20 @@ class Conv2dFn(torch.autograd.Function):
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
         dx = dx2 = dw = db = None
         if need_b and has_bias:
-            dz, db = K.act_bwd_bias(dy, y, act1)         # one pass: activation backward + bias gradient
+            bacc = _acc(ctx.bias_ref)
+            dz, db = K.act_bwd_bias(dy, y, act1, out=bacc)         # one pass: activation backward + bias gradient
+            if bacc is not None:
+                db = None
         else:
             dz = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
         c1 = x.shape[3]
         if need_w:
             kh, kw, cin, cout_gemm = w.shape
-            dw = K.conv2d_wgrad(x, x2, dz, (kh, kw, cin, dz.shape[3]), stride, x2_scale)
-            if dz.shape[3] != cout_gemm:
+            wacc = _acc(w) if dz.shape[3] == cout_gemm else None
+            dw = K.conv2d_wgrad(x, x2, dz, (kh, kw, cin, dz.shape[3]), stride, x2_scale, out=wacc)
+            if wacc is not None:
+                dw = None
+            elif dz.shape[3] != cout_gemm:
                 dw = F.pad(dw, (0, cout_gemm - dz.shape[3]))
         if need_x:
             dx = _dgrad(dz, w, 0, c1, 1.0, stride, x.shape)
@@ -193,6 +212,7 @@ class Conv2dHFn(torch.autograd.Function):
         y = K.conv2d_h(x, wp, bias, tuple(w.shape[:2]), w.shape[3], stride=stride, x2=x2, act1=act1, cout_valid=cout_valid)
         ctx.save_for_backward(x, x2, w, y)
         ctx.meta = (stride, x2_scale, act1, bias is not None, cout_valid)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -205,16 +225,25 @@ class Conv2dHFn(torch.autograd.Function):
         if y.dtype == torch.float32:                   # head: the 3-channel gradient is fp32; pad it onto an 8-channel fp16 group
             dz32 = K.act_bwd(dy, y, act1) if act1 != K.ACT_NONE else dy
             if need_b and has_bias:
-                db = K.bias_grad(dz32)
+                bacc = _acc(ctx.bias_ref)
+                db = K.bias_grad(dz32, out=bacc)
+                if bacc is not None:
+                    db = None
             dz = K.pad_channels_h(dz32, 8)
             cols = y.shape[3]
         else:
-            dz, db = K.act_bwd_bias_h(dy, y, act1, need_b and has_bias)
+            bacc = _acc(ctx.bias_ref) if (need_b and has_bias) else None
+            dz, db = K.act_bwd_bias_h(dy, y, act1, need_b and has_bias, out=bacc)
+            if bacc is not None:
+                db = None
             cols = None
         dx = dx2 = dw = None
         c1 = x.shape[3]
         if need_w:
-            dw = K.conv2d_wgrad_h(x, x2, dz, tuple(w.shape), stride, x2_scale, cout_valid=cols)
+            wacc = _acc(w)
+            dw = K.conv2d_wgrad_h(x, x2, dz, tuple(w.shape), stride, x2_scale, cout_valid=cols, out=wacc)
+            if wacc is not None:
+                dw = None
         if need_x:
             dx = _dgrad_h(dz, w, 0, c1, 1.0, stride, x.shape)
         if need_x2 and x2 is not None:
@@ -237,12 +266,18 @@ class BatchNormTrainFn(torch.autograd.Function):
         y = K.bn_train_apply(x, mean, var, gamma, beta, eps, relu)
         ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
         ctx.eps = eps
+        ctx.beta_ref = beta
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, var, gamma = ctx.saved_tensors
-        dx, dgamma, dbeta = K.bn_bwd(_c(dy), x, y, mean, var, gamma, ctx.eps)
+        gacc, bacc = _acc(gamma), _acc(ctx.beta_ref)
+        if gacc is None or bacc is None:
+            gacc = bacc = None
+        dx, dgamma, dbeta = K.bn_bwd(_c(dy), x, y, mean, var, gamma, ctx.eps, gacc, bacc)
+        if gacc is not None:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

@@ -471,15 +471,22 @@ def _up16(c):
     return (c + 15) // 16 * 16
 
 
-def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
+def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
     """dW [kh,kw,C1+C2,Cout] of conv(concat[x, x2_scale*x2], W) given dz = dL/d(conv output).
 
     Channel counts that are not multiples of 16 (3/4-channel images, 3-channel heads) are zero-padded so
-    that the layer runs on the MFMA weight-gradient tiles; the true rows / columns are sliced out."""
+    that the layer runs on the MFMA weight-gradient tiles; the true rows / columns are sliced out.
+    `out`: a gradient buffer of shape w_shape to ACCUMULATE into (the kernels add with atomics anyway): no zero fill and no
+    separate add -- used for variables whose .grad is a view of the flat gradient buffer (pipeline.FlatParams)."""
     kh, kw, cin, cout = w_shape
     c1 = x.shape[3]
     c2 = 0 if x2 is None else x2.shape[3]
+    if out is not None and (tuple(out.shape) != tuple(w_shape) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise ValueError("conv2d_wgrad: out must be a contiguous float32 tensor of shape %s" % (tuple(w_shape),))
     if c1 % 16 or c2 % 16 or cout % 16:
+        if out is not None:
+            out.add_(conv2d_wgrad(x, x2, dz, w_shape, stride, x2_scale))      # padded layers: sliced result, parameter-sized add
+            return out
         c1p, c2p, coutp = _up16(c1), (_up16(c2) if c2 else 0), _up16(cout)
         dwp = conv2d_wgrad(pad_channels(x, c1p), None if x2 is None else pad_channels(x2, c2p), pad_channels(dz, coutp),
                            (kh, kw, c1p + c2p, coutp), stride, x2_scale)
@@ -496,9 +503,9 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
             and cout % 64 == 0 and cin == c1 + c2 and cout == dz.shape[3] and tuple(dz.shape[:3]) == tuple(x.shape[:3])):
         # Winograd-domain weight gradient (csrc/wgrad_winograd.hip): 2.25x fewer MFMAs than the direct form
         n, h, w, _ = x.shape
-        dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+        dw = out if out is not None else torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
         for src, cx, off, sc in ((x, c1, 0, 1.0),) + (((_d(x2), c2, c1, float(x2_scale)),) if x2 is not None else ()):
-            du = torch.zeros((16, cx, cout), device=x.device, dtype=torch.float32)
+            du = torch.empty((16, cx, cout), device=x.device, dtype=torch.float32)       # scratch, zeroed by the library call
             _lib.check(lib.shdr_conv2d_wgrad_winograd_f32(_ptr(src), _ptr(dz), _ptr(du), _ptr(dw), n, h, w, cx, cout, cin, off, sc,
                                                           _stream()), "shdr_conv2d_wgrad_winograd_f32")
         return dw
@@ -509,7 +516,7 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0):
     d.algo = _AUTO_ALGO[PRECISION]
     if tuple(dz.shape[:3]) != (x.shape[0], d.Ho, d.Wo):
         raise ValueError("conv2d_wgrad: dz spatial shape mismatch")
-    dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
     _lib.check(lib.shdr_conv2d_wgrad_f32(ctypes.byref(d), _ptr(x), 0, _ptr(dz), _ptr(dw), _stream()), "shdr_conv2d_wgrad_f32")
     if x2 is not None:
         _lib.check(lib.shdr_conv2d_wgrad_f32(ctypes.byref(d), _ptr(_d(x2)), 1, _ptr(dz), _ptr(dw), _stream()),
@@ -528,28 +535,28 @@ def filter_transform(w, c_begin, c_count, scale=1.0):
     return wt
 
 
-def bias_grad(dz):
+def bias_grad(dz, out=None):
     lib = _lib.load()
     dz = _chk(_d(dz), "dz")
     c = dz.shape[-1]
-    db = torch.zeros(c, device=dz.device, dtype=torch.float32)
+    db = out if out is not None else torch.zeros(c, device=dz.device, dtype=torch.float32)
     _lib.check(lib.shdr_bias_grad_f32(_ptr(dz), _ptr(db), dz.numel() // c, c, _stream()), "shdr_bias_grad_f32")
     return db
 
 
-def act_bwd_bias(dy, y, act):
+def act_bwd_bias(dy, y, act, out=None):
     """(dz, db) of y = act(z + bias): dz = dy * act'(y), db = sum over pixels of dz -- one fused pass when the channel
-    count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise"""
+    count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise.  `out`: gradient buffer to accumulate db into."""
     if _is_h(dy):
-        return act_bwd_bias_h(dy, y, act, True)
+        return act_bwd_bias_h(dy, y, act, True, out)
     dy = _chk(_d(dy), "dy")
     c = dy.shape[-1]
     q = c // 4
     if c % 4 or q > 256 or q & (q - 1):
         dz = act_bwd(dy, y, act) if act != ACT_NONE else dy
-        return dz, bias_grad(dz)
+        return dz, bias_grad(dz, out)
     lib = _lib.load()
-    db = torch.zeros(c, device=dy.device, dtype=torch.float32)
+    db = out if out is not None else torch.zeros(c, device=dy.device, dtype=torch.float32)
     if act == ACT_NONE:
         dz, yp, zp = dy, None, None
     else:
@@ -696,13 +703,14 @@ def bn_train_apply(x, mean, var, gamma, beta, eps, relu):
     return y
 
 
-def bn_bwd(dy, x, y_relu, mean, var, gamma, eps):
+def bn_bwd(dy, x, y_relu, mean, var, gamma, eps, dgamma_out=None, dbeta_out=None):
+    """(dx, dgamma, dbeta); dgamma_out / dbeta_out: gradient buffers to accumulate into instead of fresh zero tensors"""
     lib = _lib.load()
     h = _is_h(x)
     dy, x = (_chkh(_d(dy), "dy"), _chkh(_d(x), "x")) if h else (_chk(_d(dy), "dy"), _chk(_d(x), "x"))
     c = x.shape[-1]
-    dgamma = torch.zeros(c, device=x.device, dtype=torch.float32)
-    dbeta = torch.zeros(c, device=x.device, dtype=torch.float32)
+    dgamma = dgamma_out if dgamma_out is not None else torch.zeros(c, device=x.device, dtype=torch.float32)
+    dbeta = dbeta_out if dbeta_out is not None else torch.zeros(c, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     ws = _bn_ws(c, x.device)
     fn = "shdr_bn_bwd_f16" if h else "shdr_bn_bwd_f32"
@@ -1026,8 +1034,9 @@ def conv2d_h(x, wp, bias, khw, cout_gemm, stride=1, x2=None, act1=ACT_NONE, cout
     return y
 
 
-def conv2d_wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None):
-    """dW [kh,kw,C1+C2,Cout] (fp32) of conv(concat[x, x2_scale*x2], W) from fp16 x / x2 / dz; columns >= cout_valid stay zero"""
+def conv2d_wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None, out=None):
+    """dW [kh,kw,C1+C2,Cout] (fp32) of conv(concat[x, x2_scale*x2], W) from fp16 x / x2 / dz; columns >= cout_valid stay zero.
+    `out`: gradient buffer of that shape to accumulate into."""
     lib = _lib.load()
     kh, kw, cin, cout = w_shape
     x, dz = _chkh(_d(x), "x"), _chkh(_d(dz), "dz")
@@ -1039,7 +1048,9 @@ def conv2d_wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None):
     d.x2_scale = float(x2_scale)
     if tuple(dz.shape[:3]) != (x.shape[0], d.Ho, d.Wo):
         raise ValueError("conv2d_wgrad_h: dz spatial shape mismatch")
-    dw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+    if out is not None and (tuple(out.shape) != tuple(w_shape) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise ValueError("conv2d_wgrad_h: out must be a contiguous float32 tensor of shape %s" % (tuple(w_shape),))
+    dw = out if out is not None else torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
     _lib.check(lib.shdr_conv2d_wgrad_f16(ctypes.byref(d), _ptr(x), 0, _ptr(dz), dz.shape[3], c1, c2, _ptr(dw), _stream()),
                "shdr_conv2d_wgrad_f16")
     if x2 is not None:
@@ -1048,12 +1059,13 @@ def conv2d_wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None):
     return dw
 
 
-def act_bwd_bias_h(dy, y, act, want_db):
-    """(dz, db) on fp16 tensors: dz = dy * act'(y) (dy itself when act is NONE), db = sum over pixels of dz in fp32 (or None)"""
+def act_bwd_bias_h(dy, y, act, want_db, out=None):
+    """(dz, db) on fp16 tensors: dz = dy * act'(y) (dy itself when act is NONE), db = sum over pixels of dz in fp32 (or None);
+    `out`: gradient buffer to accumulate db into"""
     lib = _lib.load()
     dy = _chkh(_d(dy), "dy")
     c = dy.shape[-1]
-    db = torch.zeros(c, device=dy.device, dtype=torch.float32) if want_db else None
+    db = (out if out is not None else torch.zeros(c, device=dy.device, dtype=torch.float32)) if want_db else None
     if act == ACT_NONE:
         if want_db:
             _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), None, None, _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f16")

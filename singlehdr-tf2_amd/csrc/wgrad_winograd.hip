@@ -241,6 +241,9 @@ extern "C" int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, f
   SHDR_REQUIRE(shdr::aligned16(x) && shdr::aligned16(dz), SHDR_E_ALIGN, "wgrad_winograd: x and dz must be 16-byte aligned");
   SHDR_REQUIRE((long)N * H * W * Cx < (1L << 32) && (long)N * H * W * Cout < (1L << 32), SHDR_E_SHAPE,
                "wgrad_winograd: tensor with more than 2^32 elements");
+  // du is scratch of this call: zeroed here, in stream order (the caller hands over uninitialised memory)
+  if (hipMemsetAsync(du, 0, sizeof(float) * 16 * (size_t)Cx * Cout, reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+    return shdr::fail(SHDR_E_LAUNCH, "wgrad_winograd: memset of the dU scratch failed");
   WinoWgradArgs a{};
   a.x = x; a.dz = dz; a.du = du;
   a.N = N; a.H = H; a.W = W; a.Cx = Cx; a.Cout = Cout;

@@ -134,6 +134,7 @@ class FlatParams:
                 self.flat[o:o + k].copy_(v.detach().reshape(-1))
                 v.data = self.flat[o:o + k].view(v.shape)       # the variable now aliases the flat buffer
                 v.grad = self.grad[o:o + k].view(v.shape)       # autograd accumulates in place
+                v._shdr_accum = True                            # ...and the backward kernels add into it directly (_autograd._acc)
         self.numel = n                                          # padded length of the flat buffers
         self.num_params = sum(v.numel() for v in self.variables)
 
