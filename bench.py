@@ -29,6 +29,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_{32x32x2,16x16x4}_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+TRAFFIC_FILE = "r02_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_traffic.json")) else "r01_traffic.json"
 
 
 def parse_args():
@@ -97,6 +99,90 @@ def conv_variant(w, x, x2, algo, stride=1):
     return "conv_mfma_dma_kernel<128,%d>" % bn
 
 
+def host_cores():
+    """CPU threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a container
+    the affinity of the whole host but the quota of its share -- hundreds of OpenMP threads spinning on 16 CPUs' worth of time
+    take minutes per convolution)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 32))
+
+
+def progress(msg):
+    """one line on stderr per leg: the one JSON line on stdout stays alone, and a long run is never silent"""
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def fp16_roofline(K, fstep, ldr, hdr):
+    """Per-launch HIP-event timing of the fp16 conv kernels inside ONE extra fine-tuning step (on the launch stream): the
+    dominant kernel family by time, its executed = algorithmic FLOPs (no Winograd here) against the dense fp16 MFMA peak."""
+    import ctypes
+    lib = K._lib.load()
+    recs = []
+    orig_c, orig_w = K.conv2d_h, K.conv2d_wgrad_h
+
+    def conv_h(x, wp, bias, khw, cout_gemm, stride=1, x2=None, act1=0, cout_valid=None, pad=None, out_hw=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_c(x, wp, bias, khw, cout_gemm, stride=stride, x2=x2, act1=act1, cout_valid=cout_valid, pad=pad, out_hw=out_hw)
+        e1.record()
+        c2 = 0 if x2 is None else x2.shape[3]
+        d = K._conv_desc_h(x.shape, c2, khw, cout_gemm, stride, None, pad, out_hw)
+        if lib.shdr_conv2d_patch_ok_f16(ctypes.byref(d)):
+            label = "conv_f16_patch_kernel"
+        else:
+            label = "conv_f16_kernel<%s>" % ("128,128" if cout_gemm % 128 == 0 else "256,64" if cout_gemm % 64 == 0 else
+                                              "256,32" if cout_gemm % 32 == 0 else "256,16")
+        recs.append((label, 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * (x.shape[3] + c2) * cout_gemm * khw[0] * khw[1], e0, e1))
+        return y
+
+    def wgrad_h(x, x2, dz, w_shape, stride=1, x2_scale=1.0, cout_valid=None, out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dw = orig_w(x, x2, dz, w_shape, stride, x2_scale, cout_valid=cout_valid, out=out)
+        e1.record()
+        c2 = 0 if x2 is None else x2.shape[3]
+        d = K._conv_desc_h(x.shape, c2, tuple(w_shape[:2]), w_shape[3], stride, cout_valid)
+        label = "wgrad_f16_alltaps_kernel" if lib.shdr_conv2d_wgrad_alltaps_ok_f16(ctypes.byref(d), 0, dz.shape[3]) else "wgrad_f16_kernel"
+        recs.append((label, 2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * w_shape[2] * w_shape[3] * w_shape[0] * w_shape[1], e0, e1))
+        return dw
+
+    K.conv2d_h, K.conv2d_wgrad_h = conv_h, wgrad_h
+    try:
+        fstep(ldr, hdr, apply=False)
+        torch.cuda.synchronize()
+    finally:
+        K.conv2d_h, K.conv2d_wgrad_h = orig_c, orig_w
+    agg = {}
+    for label, fl, e0, e1 in recs:
+        a = agg.setdefault(label, [0.0, 0.0, 0])
+        a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+    dom = max(agg, key=lambda k: agg[k][1])
+    fl, sec, cnt = agg[dom]
+    tot_fl, tot_sec = sum(a[0] for a in agg.values()), sum(a[1] for a in agg.values())
+    return {"bound": "mfma", "kernel": dom, "achieved": round(fl / sec / 1e12, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / sec / 1e12 / F16_MFMA_PEAK_TFLOPS, 4), "launches_per_step": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 2), "traffic": None,
+            "all_conv": {"tflops": round(tot_fl / tot_sec / 1e12, 1), "ms_per_step": round(tot_sec * 1e3, 2),
+                         "gflop_per_step": round(tot_fl / 1e9, 1)},
+            "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] * 1e3, 2), "launches_per_step": v[2]}
+                           for k, v in sorted(agg.items())}}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +235,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(out).all())
+    if rank == 0:
+        progress("inference leg done: %.2f ms/step" % (dt / args.steps * 1e3))
     n_gpus = world
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * n_gpus * args.steps / dt
@@ -233,6 +321,7 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream ----------
     if rank == 0 and not args.no_roofline:
+        progress("roofline leg (per-launch HIP events)")
         try:
             records = []     # (kernel label, flops, e0, e1, description, nested)
             orig = K.conv2d
@@ -323,7 +412,7 @@ def main():
             # the process it runs in) with the same workload -- see profiles/r01_traffic.json for the recipe
             traffic = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                     tk = json.load(f)["kernels"]
                 if dom.startswith("conv_mfma"):
                     key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
@@ -335,8 +424,16 @@ def main():
                 pass
             result["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                # SURVEY.md section 8(d) convention: the reference layers' direct-form FLOPs, no discount for what Winograd saves
+                "frac_algorithmic": round(achieved * (2.25 if dom == "winograd_fused_kernel" else 1.0) / F32_MFMA_PEAK_TFLOPS, 4),
+                "whole_step": {"executed_gflop": round(sum(a[0] for a in agg.values()) / 1e9, 1),
+                               "executed_tflops": round(sum(a[0] for a in agg.values()) / (ms_per_step * 1e-3) / 1e12, 2),
+                               "frac_executed": round(sum(a[0] for a in agg.values()) / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                               "frac_algorithmic": round(conv_total_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                               "note": "conv FLOPs of one step / the step time of the headline leg (all kernels, 2 HIP streams)"},
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % TRAFFIC_FILE,
                 "launches_per_step": cnt // reps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
                 "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
                 "flop_convention": "MFMA FLOPs the kernel executes (Winograd kernels: layer FLOPs / 2.25); per_layer_path holds the "
@@ -353,25 +450,48 @@ def main():
             result['roofline_error'] = repr(exc)[:300]
 
 
-    # ---- CPU baseline: the float32 NumPy oracle ("port") on a bounded sample, rank 0, N=1 only ------
+    # ---- CPU baseline: the fp32 torch-CPU channels-last restatement of the same path ("port": TF2-CPU is
+    #      not installable here), all host cores, 2 warm-ups, median of 5 runs, on a bounded sample of the workload (one image of
+    #      the batch); the NumPy float32 oracle checks the GPU result of that image.  Rank 0, N = 1 only. ------------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
-            from oracle import nets  # checker / baseline only -- never on the product path
+            from oracle import nets, torch_cpu  # checker / baseline only -- never on the product path
             table = np.load(os.path.join(ROOT, "singlehdr-tf2_amd", "data", "invemor_g0_hinv11.npy"))
             params = {k: {n: t.cpu().numpy() for n, t in m.state_dict().items()}
                       for k, m in (("deq", deq), ("lin", lin), ("hal", hal))}
             sample = ldr[:1].cpu().numpy()
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             torch.set_num_threads(cores)
+            progress("cpu_baseline: torch-CPU restatement on %d threads" % cores)
+            cpu_model = "unknown"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+            except OSError:
+                pass
+            cnets = {k: torch_cpu.Net(v) for k, v in params.items()}
+            times = []
+            for i in range(7):
+                t0 = time.perf_counter()
+                cpu_out = torch_cpu.inference(cnets, sample, table)
+                if i >= 2:
+                    times.append(time.perf_counter() - t0)
+            times.sort()
+            cpu_dt = times[len(times) // 2]
+            gpu_img = out[:1].cpu().numpy()
+            progress("cpu_baseline: %.2f s per image; NumPy oracle check of the GPU result" % cpu_dt)
             t0 = time.perf_counter()
             ref = nets.inference(params, sample, table, with_refinement=False)["A_pred"]
-            cpu_dt = time.perf_counter() - t0
-            err = float(np.abs(out[:1].cpu().numpy() - ref).max() / np.abs(ref).max())
+            np_dt = time.perf_counter() - t0
             result["cpu_baseline"] = {
-                "value": round(1.0 / cpu_dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                "sample": "1 image %dx%d deq+lin+hal, float32 NumPy/BLAS oracle (proxy for TF2-CPU, which is not "
-                          "installable here), %.1f s" % (args.size, args.size, cpu_dt),
-                "gpu_vs_oracle_rel_err": float("%.3g" % err),
+                "value": round(1.0 / cpu_dt, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+                "sample": "1 image %dx%d of the batch, deq+lin+hal, fp32 torch-CPU channels-last restatement (oracle/torch_cpu.py: "
+                          "proxy for TF2-CPU, which is not installable here); 2 warm-ups, median of 5 runs = %.2f s per image"
+                          % (args.size, args.size, cpu_dt),
+                "runs_s": [round(t, 3) for t in times],
+                "cpu_vs_oracle_rel_err": float("%.3g" % (np.abs(cpu_out - ref).max() / np.abs(ref).max())),
+                "gpu_vs_oracle_rel_err": float("%.3g" % (np.abs(gpu_img - ref).max() / np.abs(ref).max())),
+                "numpy_oracle_s": round(np_dt, 2),
             }
         except Exception as exc:      # an auxiliary leg must never cost the headline line
             result['cpu_baseline_error'] = repr(exc)[:300]
@@ -380,6 +500,8 @@ def main():
     # ---- joint-training leg (BASELINE configs[3]): deq+lin+hal + VGG16 perceptual loss, fwd+bwd+Adam, batch 32 x
     #      256x256 per GPU, ONE RCCL all-reduce(SUM) of the flat fp32 gradient per step (weak scaling) ------------
     if args.train_steps > 0:
+        if rank == 0:
+            progress("joint-training leg")
         del out
         torch.cuda.empty_cache()
         tg = torch.Generator().manual_seed(4 + rank)
@@ -469,10 +591,13 @@ def main():
         f_hdr = (f_hdr / (1e-6 + f_hdr.mean(dim=(1, 2, 3), keepdim=True)) * 0.5).cuda()
         gflop_img = 5360.0 * (sz / 1024.0) ** 2         # fwd 1785 GF/img, fwd+bwd ~3x
         leg = {"workload": "BASELINE configs[4]: finetune_real_dataset.py step (deq+lin+hal+ref, fwd+bwd+Adam), batch=%d x "
-                           "%dx%d tiles per GPU; fp16 = fp16 operands of v_mfma_f32_16x16x32_f16 in every conv "
-                           "fwd/dgrad/wgrad, fp32 tensors in HBM, fp32 accumulate" % (b, sz, sz),
+                           "%dx%d tiles per GPU; fp16 = NATIVE fp16 conv path: fp16 feature maps in HBM and LDS, "
+                           "v_mfma_f32_16x16x32_f16 in every conv fwd/dgrad/wgrad, fp16 BatchNorm / pooling / resize passes, "
+                           "fp32 master weights, parameter gradients and accumulation" % (b, sz, sz),
                "n_gpus": world, "scaling": "weak", "steps": args.finetune_steps}
         for prec in [p for p in args.finetune_prec.split(",") if p]:
+            if rank == 0:
+                progress("fine-tuning leg, %s" % prec)
             torch.manual_seed(777)
             nets4 = [pkg.dequantization_net.model(), pkg.linearization_net.model(), pkg.hallucination_net.model(),
                      pkg.refinement_net.model()]
@@ -494,7 +619,12 @@ def main():
             leg[prec] = {"ms_per_step": round(fdt / args.finetune_steps * 1e3, 2),
                          "images_per_s": round(b * world * args.finetune_steps / fdt, 3),
                          "tflops_algorithmic_per_gpu": round(gflop_img * b * args.finetune_steps / fdt / 1e3, 2),
-                         "loss_sum": round(floss, 3)}
+                         "loss_sum": round(floss, 3), "skipped_steps": fstep.skipped_steps}
+            if prec == "fp16" and rank == 0 and not args.no_roofline:
+                try:
+                    leg[prec]["roofline"] = fp16_roofline(K, fstep, f_ldr, f_hdr)
+                except Exception as exc:
+                    leg[prec]["roofline_error"] = repr(exc)[:300]
             del fstep, nets4, fout
             torch.cuda.empty_cache()
         result["finetune"] = leg

@@ -98,12 +98,39 @@ typedef struct shdr_conv2d_desc {
   int64_t w_batch_stride;   /* filter elements between consecutive images; 0 =   */
                             /* one filter for the whole batch.  Used by the      */
                             /* Winograd path: 16 GEMMs with 16 filters, 1 launch */
+  /* Strided placement of the output (0 / 1 = dense [N,Ho,Wo,...]): pixel (oh, ow) is written at (oh * y_pix_stride + y_off_h,
+   * ow * y_pix_stride + y_off_w) of a [N, y_H, y_W, ...] tensor; the residual is read at the same place.  Used by the input
+   * gradient of the stride-2 convolutions (linearization_net.py:12,16,91): their phases are written in place, interleaved. */
+  int32_t y_pix_stride, y_off_h, y_off_w, y_H, y_W;
 } shdr_conv2d_desc;
 
 int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
                         const float* x1, const float* x2, const float* w,
                         const float* bias, const float* scale, const float* shift,
                         const float* residual, float* y, void* stream);
+
+/* ---- dispatch below the ABI: plan / prepare / run.  algo = SHDR_ALGO_AUTO resolves to one of these kernel families from the
+ *      descriptor alone (and from whether a residual is fused), the same way in all the calls below. */
+enum {
+  SHDR_PLAN_DIRECT = 0,           /* VALU direct convolution (shapes the MFMA tile cannot take)                       */
+  SHDR_PLAN_MFMA = 1,             /* implicit GEMM: LDS-DMA / register-staged / register-A kernel, chosen by shape    */
+  SHDR_PLAN_WINOGRAD_FUSED = 2,   /* one-kernel Winograd F(2x2,3x3) (3x3 stride 1 SAME, Cin % 8 == 0, Cout % 64 == 0) */
+  SHDR_PLAN_WINOGRAD_PLANES = 3   /* three-kernel Winograd for wide layers whose Cout is not a multiple of 64         */
+};
+int shdr_conv2d_plan_f32(const shdr_conv2d_desc* d, int has_residual);
+/* The prepared form of the HWIO filter `w` for that plan: the packed Winograd transform U = G g G^T, or the plain filter with
+ * x2_scale (hallucination_net.py:101) folded into the rows of the second source.  Prepare once per filter version. */
+int64_t shdr_conv2d_prepared_filter_elems_f32(const shdr_conv2d_desc* d, int has_residual);
+int shdr_conv2d_filter_is_plain_f32(const shdr_conv2d_desc* d, int has_residual);   /* 1: `w` itself is the prepared filter */
+int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has_residual, const float* w, float* prepared, void* stream);
+/* caller-provided scratch of shdr_conv2d_fwd_prepared_f32 (0 for every plan but WINOGRAD_PLANES) */
+int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_residual);
+/* y = act2(affine(act1(conv + bias)) + residual) with the planned kernel; y_pool (optional) = MaxPool2D(2)(y) -- written by the
+ * same launch on the fused Winograd path (where y itself may then be NULL), by a pooling launch otherwise
+ * (hallucination_net.py:47-49,63-66: the conv + max-pool pairs of the encoder). */
+int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                 const float* bias, const float* scale, const float* shift, const float* residual, float* y,
+                                 float* y_pool, void* workspace, void* stream);
 
 /*
  * Convolution backward (GradientTape.gradient through Conv2D: joint_training.py:185,
@@ -122,6 +149,18 @@ int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, int which, 
  * shdr_conv2d_fwd_f32(dz, wt) with the same padding. */
 int shdr_filter_transform_f32(const float* w, float* wt, int KH, int KW, int Cin, int Cout,
                               int c_begin, int c_count, float scale, void* stream);
+/* Input gradient of the forward conv `d` w.r.t. source `which` (0: x1, 1: x2): dx [N,H,W,C_which] from dz [N,Ho,Wo,cout_valid] and
+ * the forward HWIO filter w [KH,KW,C1+C2,Cout] (GradientTape.gradient through Conv2D, joint_training.py:185).  Stride 1 (odd
+ * filters; the fused Winograd kernel where the transposed layer qualifies), 1x1 stride 2 (linearization_net.py:12,16: coarse-grid
+ * conv written to every second pixel) and general stride 2 (linearization_net.py:91: polyphase form, four stride-1 convs written in
+ * place).  Narrow tensors are zero-padded onto the MFMA tile inside.  workspace: shdr_conv2d_dgrad_workspace_bytes_f32 bytes. */
+int64_t shdr_conv2d_dgrad_workspace_bytes_f32(const shdr_conv2d_desc* d, int which);
+int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
+                          void* stream);
+/* workspace a caller must provide for one call of an op: arg = has_residual (CONV2D_FWD), source (CONV2D_DGRAD,
+ * CONV2D_WGRAD_WINOGRAD: the dU scratch), channel count (BATCHNORM: the double-precision partial sums) */
+enum { SHDR_OP_CONV2D_FWD = 0, SHDR_OP_CONV2D_DGRAD = 1, SHDR_OP_CONV2D_WGRAD_WINOGRAD = 2, SHDR_OP_BATCHNORM = 3 };
+int64_t shdr_workspace_bytes(int op, const shdr_conv2d_desc* d, int arg);
 /* db[c] += sum_p dz[p][c] (bias gradient; the caller zeroes db). */
 int shdr_bias_grad_f32(const float* dz, float* db, int64_t npix, int C, void* stream);
 
@@ -130,6 +169,8 @@ int shdr_bias_grad_f32(const float* dz, float* db, int64_t npix, int C, void* st
  * order [bin1.c0..c(C-1), bin2...].  Bit-exact w.r.t. the IEEE fp32
  * evaluation of the reference formula. */
 int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, int C, int B, void* stream);
+/* its gradient: dx[p][c] = sum_i dy[p][(i-1)*C + c] * (-+B inside the support of bin i)  (tape through linearization_net.py:336-350) */
+int shdr_soft_hist_bwd_f32(const float* x, const float* dy, float* dx, int64_t npix, int C, int B, void* stream);
 
 /* Linearization-Net front end (linearization_net.py:310-322):
  * y = concat[img(3), sobel(6), hist4(12), hist8(24), hist16(48)] zero-padded

@@ -37,55 +37,11 @@ def _acc(p):
 # ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------
-def _dgrad(dz, w, c_begin, c_count, scale, stride, x_shape):
-    """input gradient w.r.t. source channels [c_begin, c_begin+c_count) of the forward filter w"""
-    kh, kw = w.shape[0], w.shape[1]
-    cout_real = dz.shape[3]
-    if w.shape[3] != cout_real:                       # zero-padded filter columns carry no gradient
-        w = w[..., :cout_real].contiguous()
-    wt = K.filter_transform(w, c_begin, c_count, scale)        # [kh, kw, cout_real, c_count]
-    # narrow tensors (3-channel heads, 3/4-channel images) are zero-padded onto the MFMA tile
-    cin_pad = (-cout_real) % 4
-    cout_pad = (-c_count) % 16
-    if cin_pad or cout_pad:
-        wt = F.pad(wt, (0, cout_pad, 0, cin_pad))
-        dz = K.pad_channels(dz, cout_real + cin_pad)
-    cv = c_count if cout_pad else None                # None: an unpadded filter may take the Winograd kernels
-    if stride == 1:
-        return K.conv2d(dz, wt, cout_valid=cv)
-    if stride == 2 and kh == 1 and kw == 1:           # 1x1/2: dgrad on the coarse grid, then zero-upsample
-        return K.upsample_zero2(K.conv2d(dz, wt, cout_valid=cv), x_shape)
-    if stride == 2:
-        # general stride 2 (the 7x7/2 first conv of the Linearization-Net in the fine-tuning chain), polyphase form: the
-        # input pixels of parity (p, q) only see the filter taps of one parity, so dx[:, p::2, q::2] is a stride-1
-        # correlation of dz with the sub-filter wt[a0::2, b0::2] of the flipped filter -- 4 small convs with together exactly
-        # the forward's FLOPs, instead of one k x k conv over a zero-inserted dz (4x the FLOPs, 3/4 of them on zeros)
-        n, h, wd, _ = x_shape
-        _, pt = K.same_pad(h, kh, 2)
-        _, pl = K.same_pad(wd, kw, 2)
-        dx = torch.empty((n, h, wd, c_count), device=dz.device, dtype=torch.float32)
-
-        def phase(par_in, pad_fwd, k):
-            par = (par_in + pad_fwd) % 2                      # parity of the taps this input parity sees
-            taps = len(range(par, k, 2))
-            off = (par_in + pad_fwd - par) // 2
-            return k - 1 - par - 2 * (taps - 1), taps - 1 - off, taps      # first index into the flipped filter, pad, taps
-        for p_ in range(2):
-            a0, pad_t, th = phase(p_, pt, kh)
-            mh = (h - p_ + 1) // 2
-            for q_ in range(2):
-                b0, pad_l, tw = phase(q_, pl, kw)
-                mw = (wd - q_ + 1) // 2
-                if mh == 0 or mw == 0:
-                    continue
-                if th == 0 or tw == 0:
-                    dx[:, p_::2, q_::2] = 0.0
-                    continue
-                sub = wt[a0::2, b0::2].contiguous()
-                dx[:, p_::2, q_::2] = K.conv2d(dz, sub, cout_valid=c_count if cout_pad else None, pad=(pad_t, pad_l),
-                                               out_hw=(mh, mw))
-        return dx
-    raise NotImplementedError("input gradient of a %dx%d stride-%d convolution is not built" % (kh, kw, stride))
+def _dgrad(dz, w, which, c1, c2, x2_scale, stride, x_shape):
+    """input gradient w.r.t. source `which` of the forward filter w: one library call -- the decompositions (filter flip and
+    slice, zero-padding of narrow tensors, Winograd, 1x1 / 2 on the coarse grid, polyphase 7x7 / 2) live below the C ABI
+    (csrc/conv_plan.hip: shdr_conv2d_dgrad_f32)"""
+    return K.conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride, x2_scale)
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -134,10 +90,11 @@ class Conv2dFn(torch.autograd.Function):
                 dw = None
             elif dz.shape[3] != cout_gemm:
                 dw = F.pad(dw, (0, cout_gemm - dz.shape[3]))
+        c2 = 0 if x2 is None else x2.shape[3]
         if need_x:
-            dx = _dgrad(dz, w, 0, c1, 1.0, stride, x.shape)
+            dx = _dgrad(dz, w, 0, c1, c2, x2_scale, stride, tuple(x.shape))
         if need_x2 and x2 is not None:
-            dx2 = _dgrad(dz, w, c1, x2.shape[3], x2_scale, stride, x2.shape)
+            dx2 = _dgrad(dz, w, 1, c1, c2, x2_scale, stride, tuple(x2.shape))
         return dx, dx2, dw, db, None, None, None, None, None
 
 

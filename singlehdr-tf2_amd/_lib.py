@@ -26,7 +26,9 @@ class ConvDesc(ctypes.Structure):
                 ("act1", ctypes.c_int32), ("act2", ctypes.c_int32),
                 ("res_cstride", ctypes.c_int32), ("y_cstride", ctypes.c_int32),
                 ("algo", ctypes.c_int32), ("cout_valid", ctypes.c_int32),
-                ("w_batch_stride", ctypes.c_int64)]
+                ("w_batch_stride", ctypes.c_int64),
+                ("y_pix_stride", ctypes.c_int32), ("y_off_h", ctypes.c_int32), ("y_off_w", ctypes.c_int32),
+                ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/shdr.h
@@ -50,6 +52,16 @@ SIGNATURES = {
     "shdr_crc32c": (ctypes.c_uint32, [c_ptr, ctypes.c_uint64, ctypes.c_uint32]),
     "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_conv2d_plan_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_prepared_filter_elems_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_filter_is_plain_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_prepare_filter_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr]),
+    "shdr_conv2d_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_fwd_prepared_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 11),
+    "shdr_conv2d_dgrad_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_dgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "shdr_workspace_bytes": (c_i64, [c_int, ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_soft_hist_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     "shdr_filter_transform_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr]),
     "shdr_bias_grad_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),

@@ -22,22 +22,7 @@ def _needs_grad(*tensors):
         isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
-WINOGRAD = True   # route wide 3x3 stride-1 convs through Winograd F(2x2,3x3) (see conv2d_winograd)
-
-
-def winograd_pays(cin, cout):
-    """Measured on MI355X (tools/wino_bench.py, batch 16): the Winograd path (2.25x fewer MFMA FLOPs, but
-    4x-expanded V / M planes through HBM) beats the direct kernel from 128->256 / 256->128 channels up."""
-    return cin % 32 == 0 and cout % 16 == 0 and min(cin, cout) >= 128 and cin * cout >= 32768
-
-
-def winograd_path(cin, cout):
-    """Which Winograd form a 3x3 / stride-1 layer takes (tools/wino_bench.py, batch 16 on MI355X): the one-kernel fused form
-    beats the direct kernel (+55..75 %) and the three-kernel form (+3..150 %) on every shape it accepts; the three-kernel
-    form stays for wide layers whose Cout is not a multiple of 64."""
-    if cin % 8 == 0 and cout % 64 == 0 and cin >= 32:
-        return "fused"
-    return "planes" if winograd_pays(cin, cout) else None
+WINOGRAD = True   # False: ask the library for the plain (non-Winograd) kernels only (experiments, tests)
 
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -158,14 +143,16 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
         # `lin(x, training=False)` while fine-tuning with frozen BatchNorm statistics: recorded as conv + affine/join/activation,
         # two tape entries, instead of silently returning a tensor that is cut off from the graph.
         return AUTOGRAD.affine_act(y, scale, shift, residual, act2)
-    if (WINOGRAD and algo == ALGO_AUTO and residual is None and pad is None and cout_valid is None
-            and out is None and w_batch_stride == 0 and stride == 1 and tuple(w.shape[:2]) == (3, 3)
-            and (x2 is None or (x2_scale == 1.0 and x2.shape[3] == x.shape[3] and x.shape[3] % 8 == 0))):
-        path = winograd_path(w.shape[2], w.shape[3])
-        if path == "fused":
-            return conv2d_winograd_fused(x, _packed_filter(w), bias, act1, scale, shift, act2, x2=x2)
-        if path == "planes" and x2 is None:
-            return conv2d_winograd(x, winograd_filter(w), bias, act1, scale, shift, act2)
+    return _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, act2, algo, out, cout_valid, pad, out_hw,
+                       w_batch_stride, None)
+
+
+def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, act2, algo, out, cout_valid, pad, out_hw,
+                w_batch_stride, pool):
+    """One convolution through the C ABI.  The kernel family (one-kernel Winograd, three-kernel Winograd, register-A / LDS-DMA
+    implicit GEMM, direct) is chosen BELOW the ABI (shdr_conv2d_plan_f32, csrc/conv_plan.hip); this wrapper only checks shapes,
+    caches the prepared filter of persistent variables per version and provides memory.  pool: None, True (also return
+    MaxPool2D(2)(y)) or "only"."""
     lib = _lib.load()
     x = _chk(_d(x), "x")
     w = _chk(_d(w), "w")
@@ -204,7 +191,7 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
         res_cs = residual.shape[3]
     d.res_cstride = res_cs
     if out is None:
-        out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+        out = None if pool == "only" else torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
     else:
         _chk(out, "out")
         if tuple(out.shape) != (n, ho, wo, cout):
@@ -213,10 +200,121 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
     for t, nm, ln in ((bias, "bias", cout), (scale, "scale", cout), (shift, "shift", cout)):
         if t is not None and (_chk(_d(t), nm).numel() != ln):
             raise ValueError("conv2d: %s must have %d elements" % (nm, ln))
-    rc = lib.shdr_conv2d_fwd_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(_d(bias)),
-                                 _ptr(_d(scale)), _ptr(_d(shift)), _ptr(residual), _ptr(out), _stream())
-    _lib.check(rc, "shdr_conv2d_fwd_f32")
-    return out
+    if algo != ALGO_AUTO or not WINOGRAD:
+        # explicit kernel family / reduced-precision operand modes / Winograd switched off: the plain entry point
+        if pool:
+            raise ValueError("conv2d: the pooled output needs algo AUTO")
+        rc = lib.shdr_conv2d_fwd_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(_d(bias)),
+                                     _ptr(_d(scale)), _ptr(_d(shift)), _ptr(residual), _ptr(out), _stream())
+        _lib.check(rc, "shdr_conv2d_fwd_f32")
+        return out
+    has_res = int(residual is not None)
+    prepared = _prepared_filter(lib, w, d, has_res)
+    ws = None
+    nws = int(lib.shdr_conv2d_workspace_bytes_f32(ctypes.byref(d), has_res))
+    if nws > 0:
+        ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
+    yp = None
+    if pool:
+        if ho % 2 or wo % 2:
+            raise ValueError("conv2d: pool needs even output height / width")
+        yp = torch.empty((n, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
+        if out is None and int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)) != 2:      # only the fused kernel can skip y
+            out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    rc = lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
+                                          _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _stream())
+    _lib.check(rc, "shdr_conv2d_fwd_prepared_f32")
+    if pool == "only":
+        return yp
+    return (out, yp) if pool else out
+
+
+def _prepared_filter(lib, w, d, has_res):
+    """shdr_conv2d_prepare_filter_f32(w) for the plan of this layer -- `w` itself when the library says the prepared form is the
+    plain filter; kept ON the filter tensor per version for persistent variables (requires_grad leaves: the layers' kernels,
+    frozen VGG16 constants), so an inference step prepares nothing; temporaries (transposed dgrad filters) per call.  Every kernel
+    that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
+    if int(lib.shdr_conv2d_filter_is_plain_f32(ctypes.byref(d), has_res)):
+        return w
+    persistent = (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)
+    key = None
+    if persistent:
+        key = (w._version, int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)), d.C1, d.C2, float(d.x2_scale))
+        cached = getattr(w, "_shdr_packed", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+    n = int(lib.shdr_conv2d_prepared_filter_elems_f32(ctypes.byref(d), has_res))
+    prepared = torch.empty(n, device=w.device, dtype=torch.float32)
+    _lib.check(lib.shdr_conv2d_prepare_filter_f32(ctypes.byref(d), has_res, _ptr(_d(w)), _ptr(prepared), _stream()),
+               "shdr_conv2d_prepare_filter_f32")
+    if persistent:
+        w._shdr_packed = (key, prepared)
+    return prepared
+
+
+_PLAN_NAMES = {0: "direct", 1: "mfma", 2: "fused", 3: "planes"}
+
+
+def conv2d_plan(x_shape, w_shape, c2=0, stride=1, x2_scale=1.0, has_residual=False, cout_valid=None):
+    """the kernel family shdr_conv2d_fwd_prepared_f32 runs for a SAME-padded layer: "fused" (one-kernel Winograd), "planes"
+    (three-kernel Winograd), "mfma" (register-A / LDS-DMA implicit GEMM) or "direct" -- asked from the library, not decided here"""
+    lib = _lib.load()
+    n, h, wd, c1 = x_shape
+    kh, kw, cin, cout = w_shape
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
+    d.Cout, d.KH, d.KW, d.stride = cout, kh, kw, stride
+    d.cout_valid = cout_valid or cout
+    d.Ho, d.pad_t = same_pad(h, kh, stride)
+    d.Wo, d.pad_l = same_pad(wd, kw, stride)
+    d.x2_scale = float(x2_scale)
+    d.algo = ALGO_AUTO if WINOGRAD else ALGO_MFMA
+    return _PLAN_NAMES[int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), int(has_residual)))]
+
+
+def winograd_path(cin, cout):
+    """"fused" / "planes" / None for a single-source 3x3 stride-1 layer with these channel counts (library policy)"""
+    p = conv2d_plan((1, 64, 64, cin), (3, 3, cin, cout))
+    return p if p in ("fused", "planes") else None
+
+
+def conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
+    """dx [x_shape] of the SAME-padded forward conv(concat[x1 (c1 ch), x2_scale * x2 (c2 ch)], w) w.r.t. source `which` from
+    dz = dL/d(conv output) [N,Ho,Wo,cout_valid]: ONE library call (shdr_conv2d_dgrad_f32: filter flip / slice / zero-padding,
+    Winograd where the transposed layer qualifies, 1x1 / 2 on the coarse grid, polyphase form for general stride 2)."""
+    lib = _lib.load()
+    dz, w = _chk(_d(dz), "dz"), _chk(_d(w), "w")
+    n, h, wd, cx = x_shape
+    kh, kw, cin, cout = w.shape
+    if cin != c1 + c2 or cx != (c2 if which else c1):
+        raise ValueError("conv2d_dgrad: filter %s / sources %d+%d / x %s do not match" % (tuple(w.shape), c1, c2, tuple(x_shape)))
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.C1, d.C2 = n, h, wd, c1, c2
+    d.Cout, d.KH, d.KW, d.stride = cout, kh, kw, stride
+    d.cout_valid = dz.shape[3]
+    d.Ho, d.pad_t = same_pad(h, kh, stride)
+    d.Wo, d.pad_l = same_pad(wd, kw, stride)
+    d.x2_scale = float(x2_scale)
+    d.algo = _AUTO_ALGO[PRECISION] if WINOGRAD or PRECISION != "fp32" else ALGO_MFMA
+    if tuple(dz.shape[:3]) != (n, d.Ho, d.Wo) or dz.shape[3] > cout:
+        raise ValueError("conv2d_dgrad: dz shape %s does not match the forward output" % (tuple(dz.shape),))
+    nws = int(lib.shdr_conv2d_dgrad_workspace_bytes_f32(ctypes.byref(d), int(which)))
+    if nws < 0:
+        raise ValueError("conv2d_dgrad: bad descriptor")
+    ws = torch.empty(max(nws, 16), device=dz.device, dtype=torch.uint8)
+    dx = torch.empty(tuple(x_shape), device=dz.device, dtype=torch.float32)
+    _lib.check(lib.shdr_conv2d_dgrad_f32(ctypes.byref(d), int(which), _ptr(dz), _ptr(w), _ptr(dx), _ptr(ws), _stream()),
+               "shdr_conv2d_dgrad_f32")
+    return dx
+
+
+def soft_hist_bwd(img, dy, max_bin):
+    lib = _lib.load()
+    img, dy = _chk(_d(img), "img"), _chk(_d(dy), "dy")
+    c = img.shape[-1]
+    dx = torch.empty_like(img)
+    _lib.check(lib.shdr_soft_hist_bwd_f32(_ptr(img), _ptr(dy), _ptr(dx), img.numel() // c, c, int(max_bin), _stream()), "shdr_soft_hist_bwd_f32")
+    return dx
 
 
 def _nhwc_op(fn_name, x, out_shape):
@@ -1148,11 +1246,12 @@ def _packed_filter(w):
 
 
 def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
-    """(y, MaxPool2D(2)(y)) with y = act1(conv3x3(x, w) + bias): ONE launch on the fused Winograd kernel where it applies
-    (inference, even H and W), the conv + maxpool2 pair otherwise.  keep_y=False returns the pooled tensor only."""
-    if (WINOGRAD and PRECISION == "fp32" and not _needs_grad(x, w, bias) and tuple(w.shape[:2]) == (3, 3)
-            and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and winograd_path(w.shape[2], w.shape[3]) == "fused"):
-        return conv2d_winograd_fused(x, _packed_filter(w), bias, act1, pool=True if keep_y else "only")
+    """(y, MaxPool2D(2)(y)) with y = act1(conv(x, w) + bias): ONE launch where the planned kernel is the fused Winograd kernel
+    (its epilogue writes the pooled tensor too), conv + pooling launch otherwise -- decided below the C ABI.
+    keep_y=False returns the pooled tensor only."""
+    if not _is_h(x) and not _needs_grad(x, w, bias) and PRECISION in ("fp32", "fp16") and WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+        return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, None, None, None, ACT_NONE, ALGO_AUTO, None, None, None, None, 0,
+                           True if keep_y else "only")
     y = conv2d(x, w, bias, act1=act1)
     return (y, maxpool2(y)) if keep_y else maxpool2(y)
 

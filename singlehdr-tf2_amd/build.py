@@ -20,6 +20,7 @@ LIB = os.path.join(HERE, "libshdr.so")
 SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
+    "conv_plan.hip": [],
     "conv_f16.hip": [],
     "conv_f16_patch.hip": [],
     "wgrad_f16.hip": [],

@@ -48,6 +48,9 @@ struct ConvArgs {
   long w_bstride;  // filter elements between consecutive images (0: one filter for the batch)
   int no_dma;      // force the register-staged kernel (SHDR_ALGO_MFMA_REG)
   int cout_valid;  // channels actually stored (<= Cout; the filter may be zero-padded to Cout)
+  int YH, YW, ys, yoh, yow;   // geometry of the OUTPUT tensor: pixel (oh, ow) of the conv lands at (oh * ys + yoh, ow * ys + yow) of a
+                              // [N, YH, YW, y_cs] tensor (ys = 1, offsets 0, YH = Ho, YW = Wo: dense; ys = 2: the phases of a strided
+                              // input gradient / of an up-sampling conv are written in place, interleaved)
   int prec;        // 0: exact fp32 MFMA; 1: fp16 / 2: bf16 MFMA operands (fp32 in HBM and LDS, fp32 accumulate)
   int legacy_epilogue;   // SHDR_CONV_LEGACY_EPILOGUE: store straight from the accumulator layout (comparison)
 };
@@ -81,7 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     const int r = wm * MT * 16 + mi * 16 + fi;
     const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
     if (oh >= a.Ho || ow >= a.Wo) continue;
-    const long pix = ((long)img * a.Ho + oh) * a.Wo + ow;
+    const long pix = ((long)img * a.YH + oh * a.ys + a.yoh) * a.YW + ow * a.ys + a.yow;
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int co = n0 + wn * NT * 16 + ni * 16 + 4 * fg;
@@ -155,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
     if (oh >= a.Ho || ow >= a.Wo) continue;
     const int co = n0 + 4 * q;
-    const size_t pix = ((size_t)img * a.Ho + oh) * a.Wo + ow;
+    const size_t pix = ((size_t)img * a.YH + oh * a.ys + a.yoh) * a.YW + ow * a.ys + a.yow;
     float4 v = *reinterpret_cast<const float4*>(stage + r * RS + 4 * q);
     if (a.bias) {
       const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
@@ -839,6 +842,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
     const long t = pix / a.Wo;
     const int oh = t % a.Ho;
     const int img = t / a.Ho;
+    const long opix = ((long)img * a.YH + oh * a.ys + a.yoh) * a.YW + ow * a.ys + a.yow;
     float acc[CPT];
 #pragma unroll
     for (int n = 0; n < CPT; ++n) acc[n] = 0.f;
@@ -877,9 +881,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
       if (a.bias) v += a.bias[co];
       v = shdr::act_apply(v, a.act1);
       if (a.scale) v = v * a.scale[co] + a.shift[co];
-      if (a.res) v += a.res[pix * a.res_cs + co];
+      if (a.res) v += a.res[opix * a.res_cs + co];
       v = shdr::act_apply(v, a.act2);
-      a.y[pix * a.y_cs + co] = v;
+      a.y[opix * a.y_cs + co] = v;
     }
   }
 }
@@ -1072,6 +1076,15 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   a.act1 = d->act1; a.act2 = d->act2;
   a.res_cs = d->res_cstride; a.y_cs = y_cs; a.cout_valid = cout_valid;
   a.w_bstride = d->w_batch_stride;
+  a.YH = a.Ho; a.YW = a.Wo; a.ys = 1; a.yoh = 0; a.yow = 0;
+  if (d->y_pix_stride > 1) {
+    SHDR_REQUIRE(d->y_H > 0 && d->y_W > 0 && d->y_off_h >= 0 && d->y_off_w >= 0 &&
+                     (long)(d->Ho - 1) * d->y_pix_stride + d->y_off_h < d->y_H && (long)(d->Wo - 1) * d->y_pix_stride + d->y_off_w < d->y_W,
+                 SHDR_E_SHAPE, "conv2d: strided output %dx%d (stride %d, offset %d,%d) does not fit y %dx%d", d->Ho, d->Wo,
+                 d->y_pix_stride, d->y_off_h, d->y_off_w, d->y_H, d->y_W);
+    SHDR_REQUIRE((long)d->N * d->y_H * d->y_W < (1L << 31), SHDR_E_SHAPE, "conv2d: more than 2^31 output pixels");
+    a.YH = d->y_H; a.YW = d->y_W; a.ys = d->y_pix_stride; a.yoh = d->y_off_h; a.yow = d->y_off_w;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   a.legacy_epilogue = getenv("SHDR_CONV_LEGACY_EPILOGUE") != nullptr;
 

@@ -1,0 +1,287 @@
+// Dispatch policy of the convolution BELOW the C ABI: which kernel family a layer takes, the filter
+// preparation that family needs, and the input gradient with all its decompositions.  A host that binds libshdr (TF custom op, C,
+// ctypes) calls
+//     shdr_conv2d_plan_f32 / shdr_conv2d_prepared_filter_elems_f32 / shdr_conv2d_prepare_filter_f32      once per filter version
+//     shdr_conv2d_fwd_prepared_f32                                                                        per step
+//     shdr_conv2d_dgrad_f32 (+ shdr_conv2d_dgrad_workspace_bytes_f32)                                     in the backward pass
+// and gets the one-kernel Winograd F(2x2,3x3), the register-A, the LDS-DMA or the direct kernel exactly as the Python layer of
+// this package does -- that layer holds no dispatch logic of its own any more.
+// Replaces tf.keras.layers.Conv2D / tf.nn.conv2d forward and GradientTape.gradient w.r.t. the conv input (dequantization_net.py:8-46,
+// linearization_net.py:12-101, hallucination_net.py:47-140, refinement_net.py:8-47, vgg16.py:33-35, joint_training.py:185).
+#include <stdlib.h>
+
+#include "shdr_internal.h"
+
+namespace {
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the Winograd form a 3x3 / stride-1 / SAME layer takes (measured on MI355X, tools/wino_bench.py): the one-kernel fused form beats
+// the direct kernels on every shape it accepts; the three-kernel "planes" form pays from 128 -> 256 / 256 -> 128 channels up
+int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
+  const int Ct = d->C1 + d->C2;
+  const int cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  const bool mfma_ok = d->C1 % 4 == 0 && d->C2 % 4 == 0 && d->Cout % 16 == 0;
+  if (d->algo != SHDR_ALGO_AUTO) return d->algo == SHDR_ALGO_DIRECT ? SHDR_PLAN_DIRECT : SHDR_PLAN_MFMA;
+  int pt = 0, pl = 0, ho = 0, wo = 0;
+  shdr_same_pad(d->H, d->KH, d->stride, &ho, &pt);
+  shdr_same_pad(d->W, d->KW, d->stride, &wo, &pl);
+  const bool same = d->pad_t == pt && d->pad_l == pl && d->Ho == ho && d->Wo == wo;
+  const bool wino_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && same && !has_residual && cout_valid == d->Cout &&
+                          d->w_batch_stride == 0 && d->y_pix_stride <= 1 && getenv("SHDR_NO_WINOGRAD") == nullptr;
+  if (wino_shape) {
+    const bool two_ok = d->C2 == 0 || (d->C2 == d->C1 && d->C1 % 8 == 0 && d->x2_scale == 1.0f);
+    if (two_ok && Ct % 8 == 0 && d->Cout % 64 == 0 && Ct >= 32 && (long)d->N * d->H * d->W * Ct < (1L << 32)) return SHDR_PLAN_WINOGRAD_FUSED;
+    if (d->C2 == 0 && Ct % 32 == 0 && d->Cout % 16 == 0 && (Ct < d->Cout ? Ct : d->Cout) >= 128 && (long)Ct * d->Cout >= 32768)
+      return SHDR_PLAN_WINOGRAD_PLANES;
+  }
+  return mfma_ok ? SHDR_PLAN_MFMA : SHDR_PLAN_DIRECT;
+}
+
+// prepared[k][co] = w[k][co] * (k's channel >= C1 ? x2_scale : 1): the plain HWIO filter with the skip scale folded in
+__global__ __launch_bounds__(256) void fold_x2_scale_kernel(const float* __restrict__ w, float* __restrict__ out, long total, int Ct, int C1,
+                                                            int Cout, float x2_scale) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)((e / Cout) % Ct);
+    out[e] = w[e] * (c >= C1 ? x2_scale : 1.0f);
+  }
+}
+
+// dgrad filter with slicing and zero padding in one pass:
+//   wt[kh][kw][co][ci] = scale * w[KH-1-kh][KW-1-kw][c_begin + ci][co]   for co < cout_real, ci < c_count, zero for the padded rest
+//   (co < CZ = channels per pixel of the dz tensor the conv will read, ci < CC = output channels of that conv)
+__global__ __launch_bounds__(256) void dgrad_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int Ct, int Cout,
+                                                           int cout_real, int c_begin, int c_count, int CZ, int CC, float scale) {
+  const long total = (long)KH * KW * CZ * CC;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int ci = (int)(e % CC);
+    long t = e / CC;
+    const int co = (int)(t % CZ);
+    t /= CZ;
+    const int kw = (int)(t % KW), kh = (int)(t / KW);
+    float v = 0.0f;
+    if (ci < c_count && co < cout_real) v = scale * w[(((long)(KH - 1 - kh) * KW + (KW - 1 - kw)) * Ct + c_begin + ci) * Cout + co];
+    wt[e] = v;
+  }
+}
+
+// sub[a][b][co][ci] = wt[a0 + 2a][b0 + 2b][co][ci]: the taps one input-pixel parity of a stride-2 convolution sees
+__global__ __launch_bounds__(256) void subfilter_kernel(const float* __restrict__ wt, float* __restrict__ sub, int KW, int a0, int b0, int TH, int TW,
+                                                        long cc) {
+  const long total = (long)TH * TW * cc;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e % cc;
+    const long t = e / cc;
+    const int b = (int)(t % TW), a = (int)(t / TW);
+    sub[e] = wt[((long)(a0 + 2 * a) * KW + (b0 + 2 * b)) * cc + r];
+  }
+}
+
+struct DgradGeom {
+  int c_begin, c_count, cout_real, CZ, CC;      // CZ: dz channels the conv reads (multiple of 4), CC: conv output channels (padded to 16 when narrow)
+  bool pad_dz, wino;
+  size_t off_wt, off_u, off_dz, off_sub, total;
+};
+
+DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
+  DgradGeom g{};
+  g.c_begin = which ? d->C1 : 0;
+  g.c_count = which ? d->C2 : d->C1;
+  g.cout_real = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  g.CZ = (g.cout_real + 3) / 4 * 4;
+  g.pad_dz = g.CZ != g.cout_real;
+  g.CC = g.c_count % 16 == 0 ? g.c_count : (g.c_count + 15) / 16 * 16;
+  // stride-1 3x3 layers take the fused Winograd kernel when the transposed shape qualifies (the rule of plan_of)
+  g.wino = d->algo == SHDR_ALGO_AUTO && d->stride == 1 && d->KH == 3 && d->KW == 3 && !g.pad_dz && g.CC == g.c_count && g.CZ % 8 == 0 && g.CC % 64 == 0 && g.CZ >= 32 &&
+           (long)d->N * d->Ho * d->Wo * g.CZ < (1L << 32) && getenv("SHDR_NO_WINOGRAD") == nullptr;
+  const size_t filt = (size_t)d->KH * d->KW * g.CZ * g.CC * sizeof(float);
+  size_t o = 0;
+  g.off_wt = o; o += up256(filt);
+  g.off_u = o; if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
+  g.off_dz = o; if (g.pad_dz) o += up256((size_t)d->N * d->Ho * d->Wo * g.CZ * sizeof(float));
+  g.off_sub = o; if (d->stride == 2 && !(d->KH == 1 && d->KW == 1)) o += up256(filt);
+  g.total = o;
+  return g;
+}
+
+}  // namespace
+
+extern "C" int shdr_conv2d_plan_f32(const shdr_conv2d_desc* d, int has_residual) {
+  if (!d) return -1;
+  return plan_of(d, has_residual != 0);
+}
+
+// 1 if the prepared filter of this layer is byte-identical to the HWIO filter itself (no Winograd transform, no skip scale to fold):
+// the host may then hand `w` to shdr_conv2d_fwd_prepared_f32 directly and skip the copy
+extern "C" int shdr_conv2d_filter_is_plain_f32(const shdr_conv2d_desc* d, int has_residual) {
+  if (!d) return -1;
+  const int plan = plan_of(d, has_residual != 0);
+  return (plan == SHDR_PLAN_MFMA || plan == SHDR_PLAN_DIRECT) && (d->C2 == 0 || d->x2_scale == 1.0f) ? 1 : 0;
+}
+
+extern "C" int64_t shdr_conv2d_prepared_filter_elems_f32(const shdr_conv2d_desc* d, int has_residual) {
+  if (!d) return -1;
+  const int plan = plan_of(d, has_residual != 0);
+  const int64_t Ct = d->C1 + d->C2;
+  if (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_WINOGRAD_PLANES) return 16 * Ct * d->Cout;
+  return (int64_t)d->KH * d->KW * Ct * d->Cout;
+}
+
+extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has_residual, const float* w, float* prepared, void* stream) {
+  SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "prepare_filter: null pointer");
+  const int plan = plan_of(d, has_residual != 0);
+  const int Ct = d->C1 + d->C2;
+  if (plan == SHDR_PLAN_WINOGRAD_FUSED) return shdr_winograd_filter_packed_f32(w, prepared, Ct, d->Cout, stream);
+  if (plan == SHDR_PLAN_WINOGRAD_PLANES) return shdr_winograd_filter_f32(w, prepared, Ct, d->Cout, stream);
+  const long total = (long)d->KH * d->KW * Ct * d->Cout;
+  const float sc = d->C2 > 0 ? d->x2_scale : 1.0f;
+  hipLaunchKernelGGL(fold_x2_scale_kernel, dim3(shdr::stream_grid(total)), dim3(256), 0, S(stream), w, prepared, total, Ct, d->C1, d->Cout, sc);
+  return shdr::check_launch("prepare_filter");
+}
+
+extern "C" int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_residual) {
+  if (!d) return -1;
+  if (plan_of(d, has_residual != 0) != SHDR_PLAN_WINOGRAD_PLANES) return 0;
+  const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);          // rows of each of the 16 transform planes
+  return (int64_t)(up256((size_t)16 * rows * (d->C1 + d->C2) * sizeof(float)) + up256((size_t)16 * rows * d->Cout * sizeof(float)));
+}
+
+extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                            const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
+                                            void* workspace, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_fwd_prepared: null desc / x1 / prepared filter / output");
+  SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared: the fused 2x2 max-pool needs even Ho, Wo");
+  const int plan = plan_of(d, residual != nullptr);
+  if (plan == SHDR_PLAN_WINOGRAD_FUSED)
+    return shdr_conv2d_winograd_fused2_f32(x1, x2, prepared, bias, scale, shift, y, y_pool, d->N, d->H, d->W, d->C1, d->C2, d->Cout, d->act1,
+                                           d->act2, stream);
+  SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd path");
+  int rc;
+  if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
+    SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
+    const int Cin = d->C1;
+    const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);
+    float* V = reinterpret_cast<float*>(workspace);
+    float* M = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + up256((size_t)16 * rows * Cin * sizeof(float)));
+    if ((rc = shdr_winograd_input_f32(x1, V, d->N, d->H, d->W, Cin, stream))) return rc;
+    // 16 GEMMs [rows / 16, Cin] @ [Cin, Cout] as ONE launch of the conv kernel on a "16-image" 1x1 problem with a per-image filter
+    shdr_conv2d_desc g{};
+    g.N = 16; g.H = (int)(rows / 16); g.W = 16; g.C1 = Cin; g.Cout = d->Cout; g.KH = 1; g.KW = 1; g.stride = 1;
+    g.Ho = g.H; g.Wo = g.W; g.x2_scale = 1.0f; g.algo = SHDR_ALGO_AUTO; g.w_batch_stride = (int64_t)Cin * d->Cout;
+    if ((rc = shdr_conv2d_fwd_f32(&g, V, nullptr, prepared, nullptr, nullptr, nullptr, nullptr, M, stream))) return rc;
+    rc = shdr_winograd_output_f32(M, y, bias, scale, shift, d->N, d->H, d->W, d->Cout, d->act1, d->act2, stream);
+  } else {
+    shdr_conv2d_desc g = *d;
+    g.x2_scale = 1.0f;                                   // folded into the prepared filter
+    if (plan == SHDR_PLAN_DIRECT) g.x2_scale = 1.0f;
+    rc = shdr_conv2d_fwd_f32(&g, x1, x2, prepared, bias, scale, shift, residual, y, stream);
+  }
+  if (rc) return rc;
+  if (y_pool) {
+    SHDR_REQUIRE(d->y_pix_stride <= 1, SHDR_E_SHAPE, "conv2d_fwd_prepared: no pooled output with a strided y");
+    const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+    return shdr_maxpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream);
+  }
+  return SHDR_OK;
+}
+
+extern "C" int64_t shdr_conv2d_dgrad_workspace_bytes_f32(const shdr_conv2d_desc* d, int which) {
+  if (!d || (which != 0 && !(which == 1 && d->C2 > 0))) return -1;
+  return (int64_t)dgrad_geom(d, which).total;
+}
+
+extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
+                                     void* stream) {
+  SHDR_REQUIRE(d && dz && w && dx && workspace, SHDR_E_NULL, "conv2d_dgrad: null pointer");
+  SHDR_REQUIRE(which == 0 || (which == 1 && d->C2 > 0), SHDR_E_SHAPE, "conv2d_dgrad: `which` selects x1 (0) or x2 (1)");
+  SHDR_REQUIRE(d->stride == 1 || d->stride == 2, SHDR_E_SHAPE, "conv2d_dgrad: stride %d is not built", d->stride);
+  SHDR_REQUIRE(d->stride == 2 || (d->KH % 2 == 1 && d->KW % 2 == 1), SHDR_E_SHAPE, "conv2d_dgrad: stride-1 layers need odd filter sizes");
+  SHDR_REQUIRE(shdr::aligned16(workspace) && shdr::aligned16(dz) && shdr::aligned16(dx), SHDR_E_ALIGN, "conv2d_dgrad: tensors must be 16-byte aligned");
+  const DgradGeom g = dgrad_geom(d, which);
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* wt = reinterpret_cast<float*>(ws + g.off_wt);
+  hipStream_t st = S(stream);
+  const int Ct = d->C1 + d->C2;
+  const float scale = which ? d->x2_scale : 1.0f;
+  hipLaunchKernelGGL(dgrad_filter_kernel, dim3(shdr::stream_grid((long)d->KH * d->KW * g.CZ * g.CC)), dim3(256), 0, st, w, wt, d->KH, d->KW, Ct,
+                     d->Cout, g.cout_real, g.c_begin, g.c_count, g.CZ, g.CC, scale);
+  if (int rc = shdr::check_launch("dgrad_filter")) return rc;
+  const float* dzp = dz;
+  if (g.pad_dz) {
+    float* t = reinterpret_cast<float*>(ws + g.off_dz);
+    if (int rc = shdr_pad_channels_f32(dz, t, (int64_t)d->N * d->Ho * d->Wo, g.cout_real, g.CZ, stream)) return rc;
+    dzp = t;
+  }
+  shdr_conv2d_desc c{};
+  c.N = d->N; c.H = d->Ho; c.W = d->Wo; c.C1 = g.CZ; c.C2 = 0; c.Cout = g.CC; c.stride = 1; c.x2_scale = 1.0f;
+  c.cout_valid = g.c_count; c.algo = d->algo;             // (the reduced-precision operand modes carry over to the gradient convs)
+  if (d->stride == 1) {
+    c.KH = d->KH; c.KW = d->KW; c.pad_t = (d->KH - 1) - d->pad_t; c.pad_l = (d->KW - 1) - d->pad_l; c.Ho = d->H; c.Wo = d->W;
+    if (g.wino) {
+      float* u = reinterpret_cast<float*>(ws + g.off_u);
+      if (int rc = shdr_winograd_filter_packed_f32(wt, u, g.CZ, g.CC, stream)) return rc;
+      return shdr_conv2d_winograd_fused2_f32(dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, c.N, c.H, c.W, g.CZ, 0, g.CC, SHDR_ACT_NONE,
+                                             SHDR_ACT_NONE, stream);
+    }
+    return shdr_conv2d_fwd_f32(&c, dzp, nullptr, wt, nullptr, nullptr, nullptr, nullptr, dx, stream);
+  }
+  // ---- stride 2: the conv output lands on every second pixel of dx (strided placement) -----------------------------------------
+  c.y_pix_stride = 2; c.y_H = d->H; c.y_W = d->W;
+  const size_t dx_bytes = (size_t)d->N * d->H * d->W * g.c_count * sizeof(float);
+  if (d->KH == 1 && d->KW == 1) {                         // 1x1 / 2 (linearization_net.py:12,16): dgrad on the coarse grid, zero elsewhere
+    if (hipMemsetAsync(dx, 0, dx_bytes, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_dgrad: memset failed");
+    c.KH = 1; c.KW = 1; c.pad_t = 0; c.pad_l = 0; c.Ho = d->Ho; c.Wo = d->Wo; c.y_off_h = 0; c.y_off_w = 0;
+    return shdr_conv2d_fwd_f32(&c, dzp, nullptr, wt, nullptr, nullptr, nullptr, nullptr, dx, stream);
+  }
+  // general stride 2 (the 7x7 / 2 stem, linearization_net.py:91), polyphase form: the input pixels of parity (p, q) only see the filter
+  // taps of one parity, so dx[:, p::2, q::2] is a stride-1 correlation of dz with a sub-filter of the flipped filter -- four small
+  // convs with together exactly the forward's FLOPs instead of one k x k conv over a zero-inserted dz (4x the FLOPs)
+  float* sub = reinterpret_cast<float*>(ws + g.off_sub);
+  const long cc = (long)g.CZ * g.CC;
+  auto phase = [](int par_in, int pad_fwd, int k, int* first, int* pad, int* taps) {
+    const int par = (par_in + pad_fwd) % 2;
+    int n = 0;
+    for (int t = par; t < k; t += 2) ++n;
+    const int off = (par_in + pad_fwd - par) / 2;
+    *first = k - 1 - par - 2 * (n - 1);
+    *pad = n - 1 - off;
+    *taps = n;
+  };
+  bool zeroed = false;
+  for (int p = 0; p < 2; ++p) {
+    int a0, pad_t, th;
+    phase(p, d->pad_t, d->KH, &a0, &pad_t, &th);
+    const int mh = (d->H - p + 1) / 2;
+    for (int q = 0; q < 2; ++q) {
+      int b0, pad_l, tw;
+      phase(q, d->pad_l, d->KW, &b0, &pad_l, &tw);
+      const int mw = (d->W - q + 1) / 2;
+      if (mh == 0 || mw == 0) continue;
+      if (th == 0 || tw == 0) {                            // this parity sees no tap: its pixels are zero
+        if (!zeroed) {
+          SHDR_REQUIRE(p == 0 && q == 0, SHDR_E_SHAPE, "conv2d_dgrad: an empty phase after a written one is not handled");
+          if (hipMemsetAsync(dx, 0, dx_bytes, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_dgrad: memset failed");
+          zeroed = true;
+        }
+        continue;
+      }
+      hipLaunchKernelGGL(subfilter_kernel, dim3(shdr::stream_grid((long)th * tw * cc)), dim3(256), 0, st, wt, sub, d->KW, a0, b0, th, tw, cc);
+      if (int rc = shdr::check_launch("subfilter")) return rc;
+      c.KH = th; c.KW = tw; c.pad_t = pad_t; c.pad_l = pad_l; c.Ho = mh; c.Wo = mw; c.y_off_h = p; c.y_off_w = q;
+      if (int rc = shdr_conv2d_fwd_f32(&c, dzp, nullptr, sub, nullptr, nullptr, nullptr, nullptr, dx, stream)) return rc;
+    }
+  }
+  return SHDR_OK;
+}
+
+// generic workspace query of the boundary: bytes the caller has to provide for one call of `op`
+extern "C" int64_t shdr_workspace_bytes(int op, const shdr_conv2d_desc* d, int arg) {
+  switch (op) {
+    case SHDR_OP_CONV2D_FWD: return shdr_conv2d_workspace_bytes_f32(d, arg);
+    case SHDR_OP_CONV2D_DGRAD: return shdr_conv2d_dgrad_workspace_bytes_f32(d, arg);
+    case SHDR_OP_CONV2D_WGRAD_WINOGRAD: return d ? (int64_t)16 * (arg ? d->C2 : d->C1) * d->Cout * (int64_t)sizeof(float) : -1;
+    case SHDR_OP_BATCHNORM: return arg > 0 ? (int64_t)2 * arg * (int64_t)sizeof(double) : -1;     // arg = channels
+    default: return -1;
+  }
+}

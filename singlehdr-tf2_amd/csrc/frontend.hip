@@ -224,6 +224,35 @@ __global__ __launch_bounds__(256) void lin_frontend_rows_kernel(const float* __r
 
 }  // namespace
 
+namespace {
+// dx[p][c] = sum_bins dy[p][(bin-1)*C + c] * dh/dx,  h = 1 - |x - centre| * B inside the support |x - centre| < 1/B (slope -+B), 0 outside
+__global__ __launch_bounds__(256) void soft_hist_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                            long n, int C, int B) {
+  const float fb = (float)B, inv_b = 1.0f / fb;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const long p = e / C;
+    const int c = (int)(e - p * C);
+    const float xv = x[e];
+    const float* g = dy + p * (long)B * C + c;
+    float acc = 0.0f;
+    for (int i = 1; i <= B; ++i) {
+      const float centre = (float)(2 * i - 1) / (float)(2 * B);
+      const float d = xv - centre;
+      if (fabsf(d) < inv_b) acc += g[(long)(i - 1) * C] * (d > 0.0f ? -fb : (d < 0.0f ? fb : 0.0f));
+    }
+    dx[e] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int shdr_soft_hist_bwd_f32(const float* x, const float* dy, float* dx, int64_t npix, int C, int B, void* stream) {
+  SHDR_REQUIRE(x && dy && dx, SHDR_E_NULL, "soft_hist_bwd: null pointer");
+  SHDR_REQUIRE(npix > 0 && C > 0 && B > 0, SHDR_E_SHAPE, "soft_hist_bwd: npix, C, B must be positive");
+  hipLaunchKernelGGL(soft_hist_bwd_kernel, dim3(shdr::stream_grid(npix * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, dy, dx,
+                     (long)npix * C, C, B);
+  return shdr::check_launch("soft_hist_bwd");
+}
+
 extern "C" int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, int C, int B,
                                       void* stream) {
   SHDR_REQUIRE(x && y, SHDR_E_NULL, "soft_hist: null pointer");

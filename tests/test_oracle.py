@@ -198,3 +198,16 @@ def test_oracle_reproduces_golden_inference(emor_table):
     out = nets.inference(params, g["ldr"].astype(np.float64), emor_table)
     for key in ("C_pred", "invcrf", "B_pred", "hal", "A_pred", "hdr"):
         np.testing.assert_allclose(out[key], g[key], rtol=2e-6, atol=2e-6, err_msg=key)
+
+
+def test_torch_cpu_baseline_equals_numpy_oracle(emor_table):
+    """oracle/torch_cpu.py (bench.py's `cpu_baseline`: the fp32 channels-last torch-CPU restatement of BASELINE.md section 4)
+    computes the function of the NumPy oracle: same seeded weights and input, deq+lin+hal inference, <= 1e-4 relative"""
+    from oracle import nets, torch_cpu
+    rng = np.random.default_rng(9)
+    P = {k: nets.init_params(getattr(nets, k + "_spec")(), 200 + i) for i, k in enumerate(("deq", "lin", "hal"))}
+    ldr = np.round(rng.random((1, 64, 96, 3)) * 255.0) / 255.0
+    want = nets.inference(P, ldr, emor_table, with_refinement=False)["A_pred"]
+    got = torch_cpu.inference({k: torch_cpu.Net(v) for k, v in P.items()}, ldr, emor_table)
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max() / np.abs(want).max()) <= 1e-4
