@@ -155,6 +155,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     MaxPool2D(2)(y)) or "only"."""
     lib = _lib.load()
     x = _chk(_d(x), "x")
+    w_var = w                          # the variable itself: its version / leaf status key the prepared-filter cache
     w = _chk(_d(w), "w")
     n, h, wd, c1 = x.shape
     kh, kw, cin, cout_gemm = w.shape
@@ -209,7 +210,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
         _lib.check(rc, "shdr_conv2d_fwd_f32")
         return out
     has_res = int(residual is not None)
-    prepared = _prepared_filter(lib, w, d, has_res)
+    prepared = _prepared_filter(lib, w_var, d, has_res)
     ws = None
     nws = int(lib.shdr_conv2d_workspace_bytes_f32(ctypes.byref(d), has_res))
     if nws > 0:
@@ -235,7 +236,7 @@ def _prepared_filter(lib, w, d, has_res):
     frozen VGG16 constants), so an inference step prepares nothing; temporaries (transposed dgrad filters) per call.  Every kernel
     that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
     if int(lib.shdr_conv2d_filter_is_plain_f32(ctypes.byref(d), has_res)):
-        return w
+        return _d(w)
     persistent = (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)
     key = None
     if persistent:

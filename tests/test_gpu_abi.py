@@ -94,8 +94,8 @@ def test_hal_layer_through_plan_prepare_run(lib):
     d2 = same_desc(lib, n, h, w, c, 0, c, 3, 1, act1=1, res_cstride=c)
     assert lib.shdr_conv2d_plan_f32(ctypes.byref(d2), 1) == 1                # SHDR_PLAN_MFMA
     assert lib.shdr_conv2d_filter_is_plain_f32(ctypes.byref(d2), 1) == 1     # the HWIO filter itself is the prepared filter
-    y2 = torch.empty_like(y)
-    check(lib, lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(d2), ptr(xd), None, ptr(wd), ptr(bd), None, None, ptr(dev(res)), ptr(y2), None,
+    y2, resd = torch.empty_like(y), dev(res)
+    check(lib, lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(d2), ptr(xd), None, ptr(wd), ptr(bd), None, None, ptr(resd), ptr(y2), None,
                                                 None, stream()))
     assert rel_err(y2.cpu().numpy(), ref + res) <= 1e-5
 
@@ -166,5 +166,7 @@ def test_dgrad_entry_point_vs_float64_reference(lib, case):
         assert nws > 0 and nws == lib.shdr_workspace_bytes(1, ctypes.byref(d), which)
         ws = torch.empty(nws, device="cuda", dtype=torch.uint8)
         dx = torch.full((n, h, w, c2 if which else c1), float("nan"), device="cuda")      # every element must be written
-        check(lib, lib.shdr_conv2d_dgrad_f32(ctypes.byref(d), which, ptr(dev(dz)), ptr(dev(wt)), ptr(dx), ptr(ws), stream()))
+        dzd, wd = dev(dz), dev(wt)                                                         # (the caller keeps its buffers alive)
+        check(lib, lib.shdr_conv2d_dgrad_f32(ctypes.byref(d), which, ptr(dzd), ptr(wd), ptr(dx), ptr(ws), stream()))
+        torch.cuda.synchronize()
         assert rel_err(dx.cpu().numpy(), t.grad.numpy()) <= 1e-5, (name, which)
