@@ -416,6 +416,9 @@ int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, int which, c
 int shdr_conv2d_patch_ok_f16(const shdr_conv2d_desc* d);
 int shdr_conv2d_fwd_patch_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias, void* y,
                               int y_is_f32, void* stream);
+int shdr_conv2d_w3_ok_f16(const shdr_conv2d_desc* d);       /* wide 3x3 / stride-1 layers: raw patch per 32-channel chunk in LDS */
+int shdr_conv2d_fwd_w3_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias, void* y,
+                           void* stream);
 int shdr_conv2d_wgrad_alltaps_ok_f16(const shdr_conv2d_desc* d, int which, int dz_channels);
 int shdr_conv2d_wgrad_alltaps_f16(const shdr_conv2d_desc* d, const void* x, int which, const void* dz, int dz_channels, int c1_rows,
                                   int c2_rows, float* dw, void* stream);

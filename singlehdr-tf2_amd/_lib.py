@@ -122,6 +122,8 @@ SIGNATURES = {
     "shdr_conv2d_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "shdr_conv2d_patch_ok_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_fwd_patch_f16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 5 + [c_int, c_ptr]),
+    "shdr_conv2d_w3_ok_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "shdr_conv2d_fwd_w3_f16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 5 + [c_ptr]),
     "shdr_conv2d_wgrad_alltaps_ok_f16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "shdr_conv2d_wgrad_alltaps_f16": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "shdr_cast_f32_to_f16": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),

@@ -337,6 +337,10 @@ extern "C" int shdr_conv2d_patch_ok_f16(const shdr_conv2d_desc* d);
 extern "C" int shdr_conv2d_fwd_patch_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias,
                                          void* y, int y_is_f32, void* stream);
 
+extern "C" int shdr_conv2d_w3_ok_f16(const shdr_conv2d_desc* d);
+extern "C" int shdr_conv2d_fwd_w3_f16(const shdr_conv2d_desc* d, const void* x1, const void* x2, const void* wp, const float* bias, void* y,
+                                      void* stream);
+
 inline bool f16_fast(int C1, int C2) { return ((C1 + C2) % 32 == 0) && (C2 == 0 || C1 % 32 == 0); }
 inline int f16_nchunks(int ntaps, int C1, int C2) {
   const int Ct = C1 + C2;
@@ -404,6 +408,8 @@ extern "C" int shdr_conv2d_fwd_f16(const shdr_conv2d_desc* d, const void* x1, co
   // narrow full-resolution layers (<= 32 channels per tap, 16 / 32 couts): raw patch + resident filter in LDS (conv_f16_patch.hip)
   if (shdr_conv2d_patch_ok_f16(d) && getenv("SHDR_NO_PATCH") == nullptr)
     return shdr_conv2d_fwd_patch_f16(d, x1, x2, wp, bias, y, y_is_f32, stream);
+  // wide 3x3 layers: raw patch per 32-channel chunk instead of nine im2col stagings (conv_f16_w3.hip)
+  if (!y_is_f32 && shdr_conv2d_w3_ok_f16(d) && getenv("SHDR_NO_W3") == nullptr) return shdr_conv2d_fwd_w3_f16(d, x1, x2, wp, bias, y, stream);
   if (a.Cout % 128 == 0) return launch_f16_k<128, 128, 2, 2>(a, st);
   if (a.Cout % 64 == 0) return launch_f16_k<256, 64, 4, 1>(a, st);
   if (a.Cout % 32 == 0) return launch_f16_k<256, 32, 4, 1>(a, st);

@@ -39,6 +39,11 @@ struct WgradHArgs {
 
 constexpr int PK = 32;
 
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int T>
 __host__ __device__ constexpr int win_swz(int p) {
   return T >= 128 ? ((p & 3) | (((p >> 3) & 1) << 2)) : T == 64 ? (((p >> 1) & 1) | (((p >> 3) & 1) << 1)) : T == 32 ? ((p >> 3) & 1) : 0;
@@ -65,13 +70,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(const WgradHArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool computing = wave < WM * WN;
   const int wm = (wave / WN) % WM, wn = wave % WN;
-  int t = blockIdx.x;
+  // 1-D grid, XCD-aware: consecutive logical ids share an XCD (and its L2), and the taps of one (tile, pixel slice) are consecutive --
+  // the nine blocks that stream the same X / dZ slice fetch it into ONE L2 instead of eight
+  const int ntaps = a.KH * a.KW;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tap = t % ntaps; t /= ntaps;
   const int tn = t % a.tiles_n; t /= a.tiles_n;
   const int tm = t % a.tiles_m; t /= a.tiles_m;
-  const int tap = t;
+  const int slice_id = t;
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int ci0 = tm * CI_T, co0 = tn * CO_T;
-  const int p_begin = blockIdx.y * a.slice;
+  const int p_begin = slice_id * a.slice;
   const int p_end = min(p_begin + a.slice, a.npix);
   const int nchunks = (p_end - p_begin + PK - 1) / PK;
   const int nstages = (nchunks + KC - 1) / KC;
@@ -238,7 +247,7 @@ int launch_wgrad_f16(WgradHArgs& a, hipStream_t st) {
   slice = (slice + KC * PK - 1) / (KC * PK) * (KC * PK);
   a.slice = (int)slice;
   const long nslices = (a.npix + slice - 1) / slice;
-  if (tiles > 0x7fffffffL || nslices > 65535) return shdr::fail(SHDR_E_SHAPE, "wgrad_f16: grid too large");
+  if (tiles * nslices > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "wgrad_f16: grid too large");
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
@@ -247,7 +256,7 @@ int launch_wgrad_f16(WgradHArgs& a, hipStream_t st) {
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
-  hipLaunchKernelGGL((wgrad_f16_kernel<CI_T, CO_T, KC>), dim3((unsigned)tiles, (unsigned)nslices), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_f16_kernel<CI_T, CO_T, KC>), dim3((unsigned)(tiles * nslices)), dim3(256), lds, st, a);
   return shdr::check_launch("wgrad_f16_kernel");
 }
 

@@ -52,6 +52,8 @@ CASES = [
     ("unet_3x3_32_16_lrelu", 2, 19, 35, 32, 0, 16, 3, 1, 2, 1.0),
     ("unet_3x3_16_32", 1, 32, 32, 16, 0, 32, 3, 1, 0, 1.0),
     ("unet_3x3_64_32_lrelu", 1, 24, 40, 64, 0, 32, 3, 1, 2, 1.0),
+    ("w3_concat_64_64_128_ragged", 2, 21, 37, 64, 64, 128, 3, 1, 2, 1.0),      # two sources, ragged tile edges
+    ("w3_3x3_32_64", 1, 48, 48, 32, 0, 64, 3, 1, 1, 1.0),                      # a single 32-channel chunk
 ]
 
 
@@ -64,9 +66,11 @@ def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case, kernels,
     name, n, h, w, c1, c2, cout, k, stride, act, x2s = case
     if kernels == "specialised":
         monkeypatch.setenv("SHDR_ALLTAPS_MIN_PIXELS", "0")
+        monkeypatch.setenv("SHDR_W3_MIN_BLOCKS", "0")             # wide 3x3 layers: the patch-per-chunk kernel (conv_f16_w3.hip)
     else:
         monkeypatch.setenv("SHDR_NO_PATCH", "1")
         monkeypatch.setenv("SHDR_NO_ALLTAPS", "1")
+        monkeypatch.setenv("SHDR_NO_W3", "1")
     K = shdr._ops
     rng = np.random.default_rng(len(name) * 17 + h)
     x = rng.normal(size=(n, h, w, c1)).astype(np.float32)

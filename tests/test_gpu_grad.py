@@ -11,7 +11,14 @@ from oracle import nets
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-NET_L2_TOL = 5e-2   # whole-net gradients, relative L2 per tensor: see test_training_gradients_are_mask_flip_sensitive
+# Whole-net gradients of the randomly initialised training-mode nets (measured on MI355X, tools/dbg/grad_err.py): the flat gradient
+# of the Hallucination-Net is within 2-4e-4 (relative L2) of the float64 reference, its worst single variable within 1.2e-3; the
+# Linearization-Net 2e-4 .. 3.4e-3 / 7.5e-3 depending on the seed -- its head routes a gradient through min() (linearization_net.py:
+# 376-380), which jumps when two neighbouring slopes of the predicted curve tie.  Bars: NET_L2_TOL per variable, WHOLE_* on the
+# flat gradient (round 1 stated 5e-2 for both).
+NET_L2_TOL = 2e-2
+WHOLE_TOL_HAL = 1e-3
+WHOLE_TOL_LIN = 5e-3
 
 
 def dev(x, grad=False):
@@ -235,16 +242,20 @@ def _grad_check(model, tparams):
     named = [(n, t) for n, t, tr in model.named_weights() if tr]
     gmax = max(float(tparams[n].grad.abs().max()) for n, _ in named)
     worst_l2, worst_max = ("", 0.0), ("", 0.0)
+    sq_d = sq_r = 0.0
     for name, t in named:
         ref = tparams[name].grad.numpy()
         assert t.grad is not None, name
         d = host(t.grad).astype(np.float64) - ref
+        sq_d += float((d ** 2).sum())
+        sq_r += float((ref ** 2).sum())
         l2 = float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-3 * gmax * np.sqrt(ref.size)))
         mx = float(np.abs(d).max() / max(np.abs(ref).max(), 1e-3 * gmax))
         if l2 > worst_l2[1]:
             worst_l2 = (name, l2)
         if mx > worst_max[1]:
             worst_max = (name, mx)
+    _grad_check.whole = float(np.sqrt(sq_d / max(sq_r, 1e-300)))      # relative L2 of the flat gradient of the whole net
     return worst_l2, worst_max
 
 
@@ -277,6 +288,7 @@ def test_linearization_net_gradients_training_bn(shdr, emor_table):
     K.diff_loss(pred, dev(inv), 0).sum().backward()
     (n2, e2), (nm, em) = _grad_check(m, tp)
     assert e2 <= NET_L2_TOL, (n2, e2, nm, em)
+    assert _grad_check.whole <= WHOLE_TOL_LIN, _grad_check.whole
 
 
 def test_hallucination_net_gradients_training_bn(shdr):
@@ -292,7 +304,8 @@ def test_hallucination_net_gradients_training_bn(shdr):
     assert rel_err(host(y), ty.detach().numpy()) <= TOL
     K.diff_loss(y, dev(tgt), 1).sum().backward()
     (n2, e2), (nm, em) = _grad_check(m, tp)
-    assert e2 <= NET_L2_TOL, (n2, e2, nm, em)
+    assert e2 <= 5e-3, (n2, e2, nm, em)
+    assert _grad_check.whole <= WHOLE_TOL_HAL, _grad_check.whole
 
 
 def test_inference_mode_networks_under_a_tape(shdr, emor_table):

@@ -74,7 +74,7 @@ def test_joint_gradients_and_flat_buffer(setup):
         got = np.concatenate([host(t.grad).ravel() for t in setup["models"][net].trainable_variables]).astype(np.float64)
         ref = np.concatenate([setup["tP"][net][n].grad.numpy().ravel() for n, _, tr in setup["models"][net].named_weights() if tr])
         worst = max(worst, np.linalg.norm(got - ref) / np.linalg.norm(ref))
-    assert worst <= 5e-2, worst                                  # see test_gpu_grad.NET_L2_TOL
+    assert worst <= 5e-3, worst                                  # per-net flat gradient, relative L2 (test_gpu_grad.py: WHOLE_TOL_*)
     # the flat gradient buffer holds exactly these gradients (alignment gaps stay zero)
     assert abs(float(step.params.grad.double().abs().sum()) -
                sum(float(t.grad.double().abs().sum()) for m in setup["models"].values() for t in m.trainable_variables)) <= 1e-6 * float(step.params.grad.double().abs().sum())
@@ -155,7 +155,7 @@ def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     want.sum().backward()
     got = torch.cat([t.grad.reshape(-1) for t in b["lin"].trainable_variables]).double().cpu()
     ref = torch.cat([tP[n].grad.reshape(-1) for n, _, tr in b["lin"].named_weights() if tr])
-    assert float((got - ref).norm() / ref.norm()) <= 5e-2                      # whole-net bar (test_gpu_grad.NET_L2_TOL)
+    assert float((got - ref).norm() / ref.norm()) <= 5e-3                      # whole-net bar (test_gpu_grad.WHOLE_TOL_LIN)
     # and the steps train: Adam 1e-4 on the step's own variables only
     before = b["deq"].trainable_variables[0].detach().clone()
     s_deq((ldr, jpeg, mask))
