@@ -460,23 +460,33 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const hf* __restrict__
       V8 mu = zero8();
       if (mode) mu = ld8f(mean + 8 * o);
       const long step = (long)gridDim.x * PL;
+      // fp32 partial sums over short runs (<= 16 pixels: their rounding is 2^-24 relative, far below the fp16 input), folded into
+      // the double accumulators once per run -- the double adds of every element made the kernel VALU-bound at ~2 TB/s
+      float f1[8], f2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; }
+      int run = 0;
       auto acc = [&](const V8& av, const V8& xv, const V8& yv) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (mode == 0) {
-            const double v = (double)av.v[j];
-            s1[j] += v; s2[j] += v * v;
+            f1[j] += av.v[j]; f2[j] += av.v[j] * av.v[j];
           } else {
             const float gg = (y && !(yv.v[j] > 0.f)) ? 0.f : av.v[j];
-            s1[j] += (double)gg; s2[j] += (double)gg * (double)(xv.v[j] - mu.v[j]);
+            f1[j] += gg; f2[j] += gg * (xv.v[j] - mu.v[j]);
           }
         }
       };
-      long p = (long)blockIdx.x * PL + pl;
-      for (; p + step < npix; p += 2 * step) {               // two vectors per operand in flight
-        V8 av[2], xv[2], yv[2];
+      auto fold = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int j = 0; j < 8; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; f1[j] = 0.f; f2[j] = 0.f; }
+        run = 0;
+      };
+      long p = (long)blockIdx.x * PL + pl;
+      for (; p + 3 * step < npix; p += 4 * step) {           // four vectors per operand in flight
+        V8 av[4], xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
           const long i = (p + u * step) * C + 8 * o;
           av[u] = ldh(a + i);
           xv[u] = av[u]; yv[u] = av[u];
@@ -485,8 +495,10 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const hf* __restrict__
             if (y) yv[u] = ldh(y + i);
           }
         }
-        acc(av[0], xv[0], yv[0]);
-        acc(av[1], xv[1], yv[1]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc(av[u], xv[u], yv[u]);
+        run += 4;
+        if (run >= 16) fold();
       }
       for (; p < npix; p += step) {
         const long i = p * C + 8 * o;
@@ -498,6 +510,7 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const hf* __restrict__
         }
         acc(a0, x0, y0);
       }
+      fold();
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { part[j][threadIdx.x] = s1[j]; part[8 + j][threadIdx.x] = s2[j]; }
