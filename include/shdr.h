@@ -102,7 +102,14 @@ typedef struct shdr_conv2d_desc {
    * ow * y_pix_stride + y_off_w) of a [N, y_H, y_W, ...] tensor; the residual is read at the same place.  Used by the input
    * gradient of the stride-2 convolutions (linearization_net.py:12,16,91): their phases are written in place, interleaved. */
   int32_t y_pix_stride, y_off_h, y_off_w, y_H, y_W;
+  /* Operator fused IN FRONT of the convolution (SHDR_PROLOGUE_*, forward calls that take a prepared filter only).
+   * SHDR_PROLOGUE_BILINEAR2X: x1 is the LOW-RES tensor [N, H/2, W/2, C1] and the convolution runs on
+   * tf.image.resize(x1, 2x, BILINEAR) (hallucination_net.py:86-88, dequantization_net.py:25-27); H, W stay the dimensions of the
+   * convolution's input, i.e. of the up-sampled image.  On the fused Winograd plan the up-sampled tensor never exists in HBM;
+   * every other plan materialises it in the workspace (shdr_conv2d_workspace_bytes_f32 accounts for it). */
+  int32_t prologue;
 } shdr_conv2d_desc;
+enum { SHDR_PROLOGUE_NONE = 0, SHDR_PROLOGUE_BILINEAR2X = 1 };
 
 int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
                         const float* x1, const float* x2, const float* w,
@@ -345,6 +352,14 @@ int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, const float* 
 int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float* u, const float* bias,
                                     const float* scale, const float* shift, float* y, float* y_pool, int N, int H, int W,
                                     int C1, int C2, int Cout, int act1, int act2, void* stream);
+
+/* The same kernel with tf.image.resize(x, 2x, BILINEAR) fused in front (hallucination_net.py:86-88, dequantization_net.py:25-27:
+ * resize + Conv2D 3x3): x is the LOW-RES tensor [N,H/2,W/2,Cin], H x W (even) the size of the up-sampled image and of
+ * y [N,H,W,Cout].  The block stages the low-res patch and expands it in LDS with the arithmetic of shdr_resize2x_fwd_f32; the
+ * up-sampled tensor is never written.  Reached through shdr_conv2d_fwd_prepared_f32 with desc.prologue = SHDR_PROLOGUE_BILINEAR2X. */
+int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const float* bias, const float* scale,
+                                       const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
+                                       int act1, int act2, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

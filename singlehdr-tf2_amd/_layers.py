@@ -146,6 +146,10 @@ class Conv2D(Layer):
     def call(self, x, **kw):
         return K.conv2d(x, self.kernel, self.bias, stride=self.strides, **kw)
 
+    def call_up2(self, x, **kw):
+        """this layer applied to tf.image.resize(x, 2x, BILINEAR): one fused kernel where the library's plan allows it"""
+        return K.conv2d_up2(x, self.kernel, self.bias, **kw)
+
 
 class BatchNormalization(Layer):
     """tf.keras.layers.BatchNormalization() with Keras defaults (eps 1e-3, momentum 0.99)."""

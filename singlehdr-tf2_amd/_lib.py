@@ -28,7 +28,8 @@ class ConvDesc(ctypes.Structure):
                 ("algo", ctypes.c_int32), ("cout_valid", ctypes.c_int32),
                 ("w_batch_stride", ctypes.c_int64),
                 ("y_pix_stride", ctypes.c_int32), ("y_off_h", ctypes.c_int32), ("y_off_w", ctypes.c_int32),
-                ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32)]
+                ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32),
+                ("prologue", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/shdr.h
@@ -46,6 +47,7 @@ SIGNATURES = {
     "shdr_flip_rot90_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_ptr]),
     "shdr_conv2d_winograd_fused_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
     "shdr_conv2d_winograd_fused2_f32": (c_int, [c_ptr] * 8 + [c_int] * 8 + [c_ptr]),
+    "shdr_conv2d_winograd_fused_up2_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
     "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),

@@ -27,6 +27,7 @@ WINOGRAD = True   # False: ask the library for the plain (non-Winograd) kernels 
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
+PROLOGUE_NONE, PROLOGUE_BILINEAR2X = 0, 1      # shdr_conv2d_desc.prologue
 ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
 
 # Precision of the conv path.
@@ -147,8 +148,20 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
                        w_batch_stride, None)
 
 
+def conv2d_up2(x, w, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):
+    """Conv2D(SAME, stride 1)(tf.image.resize(x, 2x, BILINEAR)) with the conv2d epilogue -- the `up` blocks of
+    hallucination_net.py:86-88 and dequantization_net.py:25-27.  Without a gradient tape the library fuses the resize into the
+    convolution where the plan allows it (desc.prologue, csrc/conv_plan.hip); under a tape, and in the reduced-precision operand
+    modes, it is the two recorded ops."""
+    algo = _AUTO_ALGO[PRECISION]
+    if _is_h(x) or algo != ALGO_AUTO or not WINOGRAD or _needs_grad(x, w, bias, scale, shift):
+        return conv2d(resize2x(x), w, bias, act1=act1, scale=scale, shift=shift, act2=act2)
+    return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, scale, shift, None, act2, algo, None, None, None, None, 0, None,
+                       prologue=PROLOGUE_BILINEAR2X)
+
+
 def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, act2, algo, out, cout_valid, pad, out_hw,
-                w_batch_stride, pool):
+                w_batch_stride, pool, prologue=0):
     """One convolution through the C ABI.  The kernel family (one-kernel Winograd, three-kernel Winograd, register-A / LDS-DMA
     implicit GEMM, direct) is chosen BELOW the ABI (shdr_conv2d_plan_f32, csrc/conv_plan.hip); this wrapper only checks shapes,
     caches the prepared filter of persistent variables per version and provides memory.  pool: None, True (also return
@@ -158,6 +171,8 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     w_var = w                          # the variable itself: its version / leaf status key the prepared-filter cache
     w = _chk(_d(w), "w")
     n, h, wd, c1 = x.shape
+    if prologue == PROLOGUE_BILINEAR2X:
+        h, wd = 2 * h, 2 * wd              # the descriptor describes the convolution: its input is the up-sampled image
     kh, kw, cin, cout_gemm = w.shape
     cout = cout_gemm if cout_valid is None else int(cout_valid)
     c2 = 0
@@ -183,6 +198,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     d.act1, d.act2 = act1, act2
     d.algo = algo
     d.w_batch_stride = int(w_batch_stride)
+    d.prologue = int(prologue)
     res_cs = 0
     if residual is not None:
         residual = _chk(_d(residual), "residual")

@@ -140,11 +140,21 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
   return shdr::check_launch("prepare_filter");
 }
 
+// the bilinear 2x prologue runs inside the convolution kernel on the fused Winograd plan (single source, no pooled output)
+inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) { return plan == SHDR_PLAN_WINOGRAD_FUSED && d->C2 == 0; }
+// bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)
+inline size_t up2_bytes(const shdr_conv2d_desc* d, int plan) {
+  if (d->prologue != SHDR_PROLOGUE_BILINEAR2X || up2_in_kernel(d, plan)) return 0;
+  return up256((size_t)d->N * d->H * d->W * d->C1 * sizeof(float));
+}
+
 extern "C" int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_residual) {
   if (!d) return -1;
-  if (plan_of(d, has_residual != 0) != SHDR_PLAN_WINOGRAD_PLANES) return 0;
+  const int plan = plan_of(d, has_residual != 0);
+  const size_t up = up2_bytes(d, plan);
+  if (plan != SHDR_PLAN_WINOGRAD_PLANES) return (int64_t)up;
   const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);          // rows of each of the 16 transform planes
-  return (int64_t)(up256((size_t)16 * rows * (d->C1 + d->C2) * sizeof(float)) + up256((size_t)16 * rows * d->Cout * sizeof(float)));
+  return (int64_t)(up + up256((size_t)16 * rows * (d->C1 + d->C2) * sizeof(float)) + up256((size_t)16 * rows * d->Cout * sizeof(float)));
 }
 
 extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
@@ -153,6 +163,26 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_fwd_prepared: null desc / x1 / prepared filter / output");
   SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared: the fused 2x2 max-pool needs even Ho, Wo");
   const int plan = plan_of(d, residual != nullptr);
+  if (d->prologue != SHDR_PROLOGUE_NONE) {
+    SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_BILINEAR2X, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown prologue");
+    SHDR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->C2 == 0 && x2 == nullptr, SHDR_E_SHAPE,
+                 "conv2d_fwd_prepared: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
+    if (up2_in_kernel(d, plan)) {
+      SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: the bilinear 2x prologue writes y");
+      int rcf = shdr_conv2d_winograd_fused_up2_f32(x1, prepared, bias, scale, shift, y, d->N, d->H, d->W, d->C1, d->Cout, d->act1, d->act2, stream);
+      if (rcf || !y_pool) return rcf;
+      return shdr_maxpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, d->Cout, stream);
+    }
+    // every other plan: the up-sampled tensor goes through the head of the workspace
+    SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
+    float* xu = reinterpret_cast<float*>(workspace);
+    int rcu = shdr_resize2x_fwd_f32(x1, xu, d->N, d->H / 2, d->W / 2, d->C1, stream);
+    if (rcu) return rcu;
+    shdr_conv2d_desc g = *d;
+    g.prologue = SHDR_PROLOGUE_NONE;
+    return shdr_conv2d_fwd_prepared_f32(&g, xu, nullptr, prepared, bias, scale, shift, residual, y, y_pool,
+                                        reinterpret_cast<char*>(workspace) + up256((size_t)d->N * d->H * d->W * d->C1 * sizeof(float)), stream);
+  }
   if (plan == SHDR_PLAN_WINOGRAD_FUSED)
     return shdr_conv2d_winograd_fused2_f32(x1, x2, prepared, bias, scale, shift, y, y_pool, d->N, d->H, d->W, d->C1, d->C2, d->Cout, d->act1,
                                            d->act2, stream);

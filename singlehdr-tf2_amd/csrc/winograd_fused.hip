@@ -54,6 +54,7 @@ struct WinoFusedArgs {
   int C1;                   // channels per source (= Cin, or Cin / 2 with x2)
   int tiles_x, tiles_y, nblk_m, nblk_n;
   int act1, act2;
+  int Hl, Wl;               // UP variant: x is the LOW-RES tensor [N,Hl,Wl,C1], H = 2 Hl, W = 2 Wl are the dims of the up-sampled conv input
 };
 
 constexpr int PW = 18;                           // raw patch columns (16 + 2)
@@ -81,13 +82,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int R>
+// UP = true (R = 1): tf.image.resize(x, 2x, BILINEAR) fused in front of the convolution (hallucination_net.py:86,
+// dequantization_net.py:25): the block stages the LOW-RES patch (6 x 10 pixels per 8-channel chunk, a third of the bytes) by
+// LDS-DMA into a ring of five buffers and expands it to the 10 x 18 raw patch in LDS itself -- same arithmetic, same rounding as
+// resize2x_kernel (pool.hip: horizontal lerp, then vertical, clamped taps, zeros outside the up-sampled image) -- one chunk
+// ahead of the transform that reads it.  The up-sampled tensor never exists in HBM.
+template <int R, bool UP = false>
 __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(const WinoFusedArgs a) {
   using G = WF<R>;
   constexpr int MT = G::MT;
+  static_assert(!UP || R == 1, "the up-sampling prologue is built for the 8 x 16 tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;                         // [4][RAW_FLOATS]
+  float* lrb = smem + G::PIPE_FLOATS;        // UP: [5][LR_FLOATS] low-res patches (inside the epilogue overlay's footprint)
+  constexpr int LR_FLOATS = 8 * 256;         // one 1 KiB DMA instruction per wave (waves 0, 1 carry the 120 slots, the others a zero page)
   const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)raw;
+  const unsigned lds_lr = (unsigned)(unsigned long)(lptr_t)lrb;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,11 +126,72 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     raw_ok[j] = quad < 2 && px >= 0 && px < PW && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     raw_off[j] = raw_ok[j] ? ((unsigned)(img * a.H + ih) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.C1 + 4u * quad : 0u;
   }
+  // UP: low-res patch rows oh0/2 - 1 .. oh0/2 + 4, columns ow0/2 - 1 .. ow0/2 + 8 as [quad][6][10] slots of 16 bytes
+  unsigned lr_off = 0xFFFFFFFFu;              // sentinel: this lane stages zeros
+  if (UP) {
+    const int s = wave * 64 + lane;
+    const int quad = s / 60, rem = s - quad * 60;
+    const int ly = rem / 10, lx = rem - ly * 10;
+    const int r = (oh0 >> 1) - 1 + ly, c = (ow0 >> 1) - 1 + lx;
+    const bool ok = wave < 2 && s < 120 && (unsigned)r < (unsigned)a.Hl && (unsigned)c < (unsigned)a.Wl;
+    if (ok) lr_off = ((unsigned)(img * a.Hl + r) * (unsigned)a.Wl + (unsigned)c) * (unsigned)a.C1 + 4u * quad;
+  }
+  // UP: expansion geometry, thread t < 360 owns raw slot (quad, py, px).  One packed register (the kernel sits at the 128-VGPR
+  // limit of two blocks per CU): bits 0..12 byte offset of the top-left low-res slot, 13 right tap one slot on, 14 bottom tap
+  // one row on, 15 wx = 0.25 (else 0.75), 16 wy = 0.25, 17 pixel outside the image (zeros), 18 thread takes part,
+  // 19..31 byte offset of the raw slot
+  unsigned ex_pack = 0u;
+  if (UP) {
+    const bool on = tid < 360;
+    const int t = on ? tid : 0;
+    const int quad = t / 180, rem = t - quad * 180;
+    const int py = rem / PW, px = rem - py * PW;
+    const int rf = oh0 - 1 + py, cf = ow0 - 1 + px;            // pixel of the up-sampled image
+    const bool outside = !((unsigned)rf < (unsigned)a.H && (unsigned)cf < (unsigned)a.W);
+    const int rfc = outside ? oh0 : rf, cfc = outside ? ow0 : cf;
+    const int mr = rfc >> 1, mc = cfc >> 1;
+    const int ra = (rfc & 1) ? mr : max(mr - 1, 0), rb = (rfc & 1) ? min(mr + 1, a.Hl - 1) : mr;
+    const int ca = (cfc & 1) ? mc : max(mc - 1, 0), cb = (cfc & 1) ? min(mc + 1, a.Wl - 1) : mc;
+    const int r0 = (oh0 >> 1) - 1, c0 = (ow0 >> 1) - 1;
+    const unsigned src = (unsigned)((quad * 60 + (ra - r0) * 10 + (ca - c0)) * 16);
+    const unsigned dst = (unsigned)((quad * G::QS + py * RP2 + px + ((py >> 1) & 1)) * 16);
+    ex_pack = src | ((unsigned)(cb != ca) << 13) | ((unsigned)(rb != ra) << 14) | ((unsigned)(cfc & 1) << 15) |
+              ((unsigned)(rfc & 1) << 16) | ((unsigned)outside << 17) | ((unsigned)on << 18) | (dst << 19);
+  }
   // B operands: this lane's 16 filter values of a chunk = four float4 at up[(c*4 + j)*256], j = 2*x2 + s, .xyzw = nt 0..3
   const float* ub = a.u + (size_t)(pn * 8 + wave) * nch * 1024;     // wave-uniform: SGPR base, the lane offset stays 32-bit
   // chunk c of the concatenated channel axis: both sources have C1 channels, so the pixel offsets are shared (wave-uniform
   // pointer select)
   const int nch1 = a.C1 >> 3;
+  auto dma_lr = [&](int c, int buf) {           // UP: one instruction per wave, like the raw DMA of the 8 x 16 tile (same vmcnt counts)
+    const float* p = lr_off != 0xFFFFFFFFu ? a.x + (size_t)(lr_off + 8u * (unsigned)c) : zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lrb + buf * LR_FLOATS + wave * 256), 16, 0, 0);
+  };
+  // UP: low-res(buf_lr) -> raw(buf_raw).  LDS accesses in inline asm: the compiler would order its own LDS reads behind every
+  // LDS-DMA write in flight (vmcnt(0)); the data was waited for and barrier-ordered an iteration ago.
+  auto expand = [&](int buf_lr, int buf_raw) {
+    unsigned pk = ex_pack;
+    asm volatile("" : "+v"(pk));              // unpack HERE: hoisted out of the loop the unpacked values spill (and a spill reload is a vmcnt(0))
+    if (pk & (1u << 18)) {
+      const unsigned s00 = lds_lr + (unsigned)(buf_lr * LR_FLOATS * 4) + (pk & 0x1FFFu);
+      const unsigned dx = (pk >> 9) & 16u, dy = ((pk >> 14) & 1u) * 160u;
+      const float wx = (pk & (1u << 15)) ? 0.25f : 0.75f, wy = (pk & (1u << 16)) ? 0.25f : 0.75f;
+      f32x4 q00, q01, q10, q11;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(q00), "=&v"(q01), "=&v"(q10), "=&v"(q11)
+                   : "v"(s00), "v"(s00 + dx), "v"(s00 + dy), "v"(s00 + dx + dy));
+      const bool outside = pk & (1u << 17);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = q00[e] + (q01[e] - q00[e]) * wx;        // horizontal first, then vertical: the order of resize2x_kernel
+        const float u = q10[e] + (q11[e] - q10[e]) * wx;
+        o[e] = outside ? 0.0f : t + (u - t) * wy;
+      }
+      const unsigned db = lds0 + (unsigned)(buf_raw * G::RAW_FLOATS * 4) + (pk >> 19);
+      asm volatile("ds_write_b128 %0, %1" ::"v"(db), "v"(o) : "memory");
+    }
+  };
   auto dma_raw = [&](int c, int buf) {
     const float* src = c < nch1 ? a.x : a.x2;
     const unsigned cc = (unsigned)(c < nch1 ? c : c - nch1);
@@ -169,10 +240,24 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
 #define WF_LOAD_BQ(J, BASE) \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #J "*1024" : "=v"(bq[J]) : "v"(ulb), "s"(BASE))
   WF_LOAD_BQ(0, ub); WF_LOAD_BQ(1, ub); WF_LOAD_BQ(2, ub); WF_LOAD_BQ(3, ub);
-  dma_raw(0, 0);
-  dma_raw(nch > 1 ? 1 : 0, 1);
-  dma_raw(nch > 2 ? 2 : nch - 1, 2);
-  __syncthreads();
+  if (UP) {
+    // low-res patches run TWO chunks ahead of the raw patches they expand into (a DMA issued in iteration k is landed and
+    // barrier-ordered for every wave from iteration k + 2 on): lr(c + 4) is issued where raw(c + 3) used to be
+    dma_lr(0, 0);
+    dma_lr(nch > 1 ? 1 : 0, 1);
+    dma_lr(nch > 2 ? 2 : nch - 1, 2);
+    dma_lr(nch > 3 ? 3 : nch - 1, 3);
+    __syncthreads();
+    expand(0, 0);
+    expand(1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    dma_raw(0, 0);
+    dma_raw(nch > 1 ? 1 : 0, 1);
+    dma_raw(nch > 2 ? 2 : nch - 1, 2);
+    __syncthreads();
+  }
 
   f32x2 d[MT][2][3];
   float2 v[2][MT];                            // [x2][mt]
@@ -224,7 +309,8 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   for (int c = 0; c < nch; ++c) {
     read_patch((c + 1) & 3);                  // raw(c+1): landed and barrier-ordered one iteration ago (unused after the last chunk)
     __builtin_amdgcn_sched_barrier(0);
-    dma_raw(c + 3 < nch ? c + 3 : nch - 1, (c + 3) & 3);      // unconditional: a uniform vmcnt
+    if (UP) dma_lr(c + 4 < nch ? c + 4 : nch - 1, (c + 4) % 5);
+    else dma_raw(c + 3 < nch ? c + 3 : nch - 1, (c + 3) & 3);      // unconditional: a uniform vmcnt
     __builtin_amdgcn_sched_barrier(0);
     const float* un = ub + (size_t)(c + 1 < nch ? c + 1 : c) * 1024;       // next chunk's operands (the last chunk reloads itself)
     // Four groups of 2*MT*... MFMAs, one per filter register quad j = 2*x2 + k-step.  In flight before group j, oldest first:
@@ -255,6 +341,13 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
     group(std::integral_constant<int, 3>{}); WF_LOAD_BQ(3, un);
     patch_ready();
     transform();                              // V(c+1)
+    if (UP) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(v[0][mt].x), "+v"(v[0][mt].y), "+v"(v[1][mt].x), "+v"(v[1][mt].y));
+      // raw(c+2) <- low-res(c+2) (issued two iterations ago: landed for every wave); read at the top of the next iteration
+      expand((c + 2 < nch ? c + 2 : nch - 1) % 5, (c + 2) & 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);        // drain the tail DMA / loads before the pipeline buffers become the M overlay
@@ -328,7 +421,7 @@ __global__ __launch_bounds__(512, (R == 1 ? 4 : 2)) void winograd_fused_kernel(c
   }
 }
 
-template <int R>
+template <int R, bool UP = false>
 int launch_fused(WinoFusedArgs& a, hipStream_t st) {
   a.tiles_x = (a.W + 15) / 16;
   a.tiles_y = (a.H + 8 * R - 1) / (8 * R);
@@ -336,15 +429,16 @@ int launch_fused(WinoFusedArgs& a, hipStream_t st) {
   a.nblk_n = a.Cout / 64;
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk <= 0 || nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "winograd_fused: grid of %ld blocks", nblk);
+  static_assert(!UP || WF<R>::PIPE_FLOATS + 5 * 8 * 256 <= WF<R>::LDS_BYTES / 4, "the low-res ring lives inside the epilogue overlay");
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_fused_kernel<R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_fused_kernel<R, UP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WF<R>::LDS_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
-  hipLaunchKernelGGL(winograd_fused_kernel<R>, dim3((unsigned)nblk), dim3(512), WF<R>::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((winograd_fused_kernel<R, UP>), dim3((unsigned)nblk), dim3(512), WF<R>::LDS_BYTES, st, a);
   return shdr::check_launch("winograd_fused_kernel");
 }
 
@@ -380,4 +474,24 @@ extern "C" int shdr_conv2d_winograd_fused_f32(const float* x, const float* u, co
                                               const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
                                               int act1, int act2, void* stream) {
   return shdr_conv2d_winograd_fused2_f32(x, nullptr, u, bias, scale, shift, y, nullptr, N, H, W, Cin, 0, Cout, act1, act2, stream);
+}
+
+// Conv2D 3x3 SAME stride 1 of tf.image.resize(x, 2x, BILINEAR) (hallucination_net.py:86-88, dequantization_net.py:25-27) in one
+// kernel: x is the LOW-RES tensor [N,H/2,W/2,Cin], H x W the (even) size of the up-sampled image = of y [N,H,W,Cout].
+extern "C" int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const float* bias, const float* scale,
+                                                  const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
+                                                  int act1, int act2, void* stream) {
+  SHDR_REQUIRE(x && u && y, SHDR_E_NULL, "winograd_fused_up2: null x/u/y");
+  SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "winograd_fused_up2: scale and shift come together");
+  SHDR_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, SHDR_E_SHAPE, "winograd_fused_up2: non-positive dimension");
+  SHDR_REQUIRE(H % 2 == 0 && W % 2 == 0, SHDR_E_SHAPE, "winograd_fused_up2: H, W are the up-sampled (even) dimensions");
+  SHDR_REQUIRE(Cin % 8 == 0 && Cout % 64 == 0, SHDR_E_SHAPE, "winograd_fused_up2: need Cin %% 8 == 0 and Cout %% 64 == 0");
+  SHDR_REQUIRE(shdr::aligned16(x) && shdr::aligned16(u), SHDR_E_ALIGN, "winograd_fused_up2: x and u must be 16-byte aligned");
+  SHDR_REQUIRE((long)N * H * W * Cin < (1L << 32) && 16L * Cin * Cout < (1L << 32), SHDR_E_SHAPE,
+               "winograd_fused_up2: tensor with more than 2^32 elements");
+  WinoFusedArgs a{};
+  a.x = x; a.x2 = x; a.u = u; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = nullptr;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.C1 = Cin; a.Cout = Cout; a.Hl = H / 2; a.Wl = W / 2;
+  a.act1 = act1; a.act2 = act2;
+  return launch_fused<1, true>(a, reinterpret_cast<hipStream_t>(stream));
 }

@@ -40,8 +40,7 @@ class up(Layer):
         self.conv2 = Conv2D(outChannels + skipChannels, outChannels, kernel_size, device=device)
 
     def call(self, x, skpCn):
-        x = K.resize2x(x)
-        x = self.conv1(x, act1=K.ACT_LRELU)
+        x = self.conv1.call_up2(x, act1=K.ACT_LRELU)       # resize fused into the conv without a tape (K.conv2d_up2)
         return self.conv2(x, x2=skpCn, act1=K.ACT_LRELU)
 
 

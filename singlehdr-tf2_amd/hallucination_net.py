@@ -59,13 +59,13 @@ class up(Layer):
         self.norm1 = BatchNormalization(outChannels, device=device)
 
     def call(self, x, training="training"):
-        x = K.resize2x(x)
         if is_training(training):       # relu(conv) -> batch-statistics BN -> relu, separate taped ops
-            return self.norm1.train_apply(self.conv1(x, act1=K.ACT_RELU), relu=True)
+            return self.norm1.train_apply(self.conv1(K.resize2x(x), act1=K.ACT_RELU), relu=True)
         if taping(x, self.conv1.kernel, self.norm1.gamma):     # inference mode on a tape: frozen statistics, separate tape entries
-            return self.norm1.frozen_apply(self.conv1(x, act1=K.ACT_RELU), relu=True)
+            return self.norm1.frozen_apply(self.conv1(K.resize2x(x), act1=K.ACT_RELU), relu=True)
         scale, shift = self.norm1.folded()
-        return self.conv1(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
+        # inference: resize, conv, relu, folded BN, relu in ONE kernel -- the up-sampled tensor never reaches HBM
+        return self.conv1.call_up2(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
 
 
 class skipLayer(Layer):

@@ -334,6 +334,44 @@ def test_conv2d_winograd_fused_parity(shdr, shape):
         K.winograd_filter_packed(dev(np.ascontiguousarray(wt[..., :48])))
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 128), (1, 5, 7, 32, 64), (1, 13, 18, 40, 64), (2, 1, 1, 32, 64), (1, 16, 24, 512, 128),
+                                   (1, 3, 33, 72, 192), (1, 32, 32, 128, 64), (1, 4, 9, 16, 64), (1, 6, 5, 64, 32), (1, 7, 4, 32, 16)])
+def test_conv2d_up2_fused_parity(shdr, shape):
+    """Conv2D 3x3 of tf.image.resize(x, 2x, BILINEAR) (hallucination_net.py:86-88, dequantization_net.py:25-27) with the resize
+    fused into the one-kernel Winograd (low-res patch staged by DMA, expanded in LDS): vs the float64 oracle (resize, then conv)
+    and BIT-IDENTICAL to the two-kernel path (the expansion repeats resize2x_kernel's arithmetic); ragged tiles, a 1 x 1 source,
+    2 .. 64 channel chunks; layers the fused plan does not take (Cin < 32, Cout % 64 != 0) go through the workspace."""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    up = ops.resize_bilinear_2x(x.astype(np.float64))
+    ref = oracle_conv(up, wt, b, act1=1, scale=sc, shift=sh, act2=1)
+    y = K.conv2d_up2(dev(x), dev(wt), dev(b), act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    two = K.conv2d(K.resize2x(dev(x)), dev(wt), dev(b), act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert torch.equal(y, two)
+    y0 = K.conv2d_up2(dev(x), dev(wt))
+    assert rel_err(host(y0), oracle_conv(up, wt)) <= TOL
+    fused = cin >= 32 and cout % 64 == 0
+    assert (K.conv2d_plan((n, 2 * h, 2 * w, cin), wt.shape) == "fused") == fused
+
+
+def test_conv2d_up2_under_tape_is_two_recorded_ops(shdr):
+    """with a gradient tape the fused prologue is not taken: resize and conv are recorded, the gradient reaches x and w"""
+    K = shdr._ops
+    rng = np.random.default_rng(3)
+    x = dev(rng.normal(size=(1, 4, 6, 32))).requires_grad_(True)
+    wt = dev(rng.normal(size=(3, 3, 32, 64)) / 17.0).requires_grad_(True)
+    y = K.conv2d_up2(x, wt, act1=K.ACT_RELU)
+    y.sum().backward()
+    assert x.grad is not None and wt.grad is not None and float(wt.grad.abs().sum()) > 0
+    with torch.no_grad():
+        assert torch.equal(K.conv2d_up2(x, wt, act1=K.ACT_RELU), y.detach())
+
+
 @pytest.mark.parametrize("shape", [(2, 13, 21, 32, 64), (1, 16, 32, 64, 128), (1, 9, 9, 8, 64), (1, 32, 16, 128, 64)])
 def test_conv2d_winograd_fused_two_sources(shdr, shape):
     """the fused Winograd kernel on a channel concatenation [x, x2] (skip connections of the U-Net decoders): against the
