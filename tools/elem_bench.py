@@ -15,10 +15,15 @@ def t(f, n=10):
     return e0.elapsed_time(e1) / n
 
 
-for shape in [(32, 128, 128, 64), (32, 64, 64, 256), (32, 32, 32, 512), (32, 256, 256, 64), (32, 16, 16, 1024)]:
+HALF = "--half" in sys.argv          # the fp16 twins at the fine-tuning shapes (batch 4 x 1024^2)
+SHAPES = [(4, 1024, 1024, 64), (4, 512, 512, 128), (4, 512, 512, 64), (4, 256, 256, 256), (4, 128, 128, 512), (4, 64, 64, 512),
+          (4, 1024, 1024, 16)] if HALF else [(32, 128, 128, 64), (32, 64, 64, 256), (32, 32, 32, 512), (32, 256, 256, 64), (32, 16, 16, 1024)]
+for shape in SHAPES:
     x = torch.randn(*shape, device="cuda"); dy = torch.randn_like(x); c = shape[-1]
+    if HALF:
+        x, dy = x.half(), dy.half()
     g, b = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda")
-    mb = x.numel() * 4 / 1e6
+    mb = x.numel() * x.element_size() / 1e6
     ms = t(lambda: K.bn_stats(x)); print("%-22s bn_stats        %.3f ms  %.2f TB/s" % (shape, ms, mb / ms / 1e3))
     mean, var = K.bn_stats(x)
     ms = t(lambda: K.bn_train_apply(x, mean, var, g, b, 1e-3, True)); print("%-22s bn_train_apply  %.3f ms  %.2f TB/s" % (shape, ms, 2 * mb / ms / 1e3))
