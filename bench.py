@@ -367,16 +367,33 @@ def main():
                                 "%dx%d %d+0->%d k3 s1 +pool" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3]), False))
                 return out
 
+            orig_up = K.conv2d_up2
+
+            def timed_conv_up2(x, w, bias=None, **kw):
+                # bilinear 2x + conv of the decoders' `up` blocks: ONE launch of the fused Winograd kernel (up-sampling variant) where
+                # the plan is "fused" -- timed here as that launch, with the conv layer's FLOPs --, otherwise resize2x + conv2d()
+                # [the latter recorded by timed_conv]
+                n, h, wd, c = x.shape
+                if not (K.WINOGRAD and K.conv2d_plan((n, 2 * h, 2 * wd, c), tuple(w.shape)) == "fused"):
+                    return timed_conv(K.resize2x(x), w, bias, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig_up(x, w, bias, **kw)
+                e1.record()
+                records.append(("winograd_fused_kernel", 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
+                                "%dx%d(x2) %d+0->%d k3 s1 +bilinear" % (h, wd, c, w.shape[3]), False))
+                return out
+
             reps = 3
             eager(ldr)           # the caching allocator's pool of THIS stream (the timed leg may have run on side streams)
             torch.cuda.synchronize()
-            K.conv2d, K.conv2d_maxpool2 = timed_conv, timed_conv_pool
+            K.conv2d, K.conv2d_maxpool2, K.conv2d_up2 = timed_conv, timed_conv_pool, timed_conv_up2
             try:
                 for _ in range(reps):
                     eager(ldr)
                 torch.cuda.synchronize()
             finally:
-                K.conv2d, K.conv2d_maxpool2 = orig, orig_cp
+                K.conv2d, K.conv2d_maxpool2, K.conv2d_up2 = orig, orig_cp, orig_up
             # one entry per conv call of ONE pass, timed as the median over the `reps` passes (a host-side hiccup --
             # e.g. the runtime growing its signal pool inside hipEventRecord -- shows up as GPU idle time between
             # the two events of whichever call it hits, in one pass only)
@@ -417,9 +434,10 @@ def main():
                 if dom.startswith("conv_mfma"):
                     key = dom.replace(",", ", ")[:-1]          # "conv_mfma_dma_kernel<128, 128"
                     hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(key) and k.endswith("true>")]
-                else:
-                    hits = [v["hbm_bytes_per_launch"] for k, v in tk.items() if k.startswith(dom)]
-                traffic = hits[0] if hits else None
+                    hits = [(h, 1) for h in hits[:1]]
+                else:                                          # all template variants of the kernel, weighted by their launches
+                    hits = [(v["hbm_bytes_per_launch"], v["launches"]) for k, v in tk.items() if k.startswith(dom)]
+                traffic = int(sum(b * n for b, n in hits) / sum(n for _, n in hits)) if hits else None
             except (OSError, KeyError, ValueError):
                 pass
             result["roofline"] = {
