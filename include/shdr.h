@@ -166,7 +166,11 @@ int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const float* dz,
                           void* stream);
 /* workspace a caller must provide for one call of an op: arg = has_residual (CONV2D_FWD), source (CONV2D_DGRAD,
  * CONV2D_WGRAD_WINOGRAD: the dU scratch), channel count (BATCHNORM: the double-precision partial sums) */
-enum { SHDR_OP_CONV2D_FWD = 0, SHDR_OP_CONV2D_DGRAD = 1, SHDR_OP_CONV2D_WGRAD_WINOGRAD = 2, SHDR_OP_BATCHNORM = 3 };
+enum { SHDR_OP_CONV2D_FWD = 0, SHDR_OP_CONV2D_DGRAD = 1, SHDR_OP_CONV2D_WGRAD_WINOGRAD = 2, SHDR_OP_BATCHNORM = 3,
+       SHDR_OP_ACT_BWD_BIAS = 4 /* arg = channels: one row of C floats per reduction block; optional (ws = NULL: atomics) */ };
+/* BATCHNORM workspace = 2 C (1 + SHDR_BN_MAX_BLOCKS) doubles: the sums and one partial row per reduction block (the fp16 kernels
+ * reduce without atomics and without a memset; the fp32 kernels use the first 2 C doubles) */
+#define SHDR_BN_MAX_BLOCKS 1024
 int64_t shdr_workspace_bytes(int op, const shdr_conv2d_desc* d, int arg);
 /* db[c] += sum_p dz[p][c] (bias gradient; the caller zeroes db). */
 int shdr_bias_grad_f32(const float* dz, float* db, int64_t npix, int C, void* stream);
@@ -256,8 +260,9 @@ int shdr_gap_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* str
 /* dx[n,2i,2j,:] = dy[n,i,j,:], zero elsewhere (input gradient of a 1x1 stride-2 conv). */
 int shdr_upsample_zero2_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* BatchNormalization, training mode (linearization_net.py:13-25, hallucination_net.py:82,122,141):
- * batch mean / biased variance over (N,H,W) accumulated in double (ws = 2*C doubles of caller
- * workspace); optional Keras moving-average update (momentum 0.99, unbiased variance). */
+ * batch mean / biased variance over (N,H,W) accumulated in double (ws = caller workspace of
+ * shdr_workspace_bytes(SHDR_OP_BATCHNORM, NULL, C) bytes: the 2*C sums + one partial row per reduction
+ * block, no atomics); optional Keras moving-average update (momentum 0.99, unbiased variance). */
 int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float* var, float* moving_mean,
                       float* moving_var, int64_t npix, int C, float momentum, void* stream);
 int shdr_bn_train_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
@@ -331,7 +336,7 @@ int shdr_mean_norm_bwd_f32(const float* g, const float* sum, const float* gdot, 
  * pass (the caller zeroes db).  act == SHDR_ACT_NONE: dz is not written (dz = dy) and only db is accumulated.
  * C / 4 must be a power of two <= 256.  Replaces the act_bwd + bias_grad pair of GradientTape.gradient through
  * tf.nn.leaky_relu / relu(conv(x) + b) (dequantization_net.py:13-14, hallucination_net.py:48-52). */
-int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, int64_t npix, int C, int act, void* stream);
+int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, float* ws, int64_t npix, int C, int act, void* stream);
 
 /* U = G g G^T of a 3x3 HWIO filter in the operand order of the fused kernel (one coalesced float4 per lane, chunk and
  * operand group; layout documented at winograd_filter_packed_kernel).  up: 16*Cin*Cout floats. */
@@ -449,7 +454,7 @@ int shdr_pack3_f16(const float* s0, const float* s1, const float* s2, const floa
 int shdr_unpack3_f16(const void* y, float* o0, float* o1, float* o2, float* o3, int nout, int channels, int64_t npix,
                      int vgg_preprocess_bwd, void* stream);
 /* dz = dy * act'(y) (skipped for act NONE), db[c] += sum_p dz[p][c] (skipped when db is NULL) */
-int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, float* db, int64_t npix, int C, int act, void* stream);
+int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, float* db, float* ws, int64_t npix, int C, int act, void* stream);
 /* y = a + b, optionally relu (residual joins of linearization_net.py:45-47,80-82; gradient accumulation at fan-out points) */
 int shdr_add_f16(const void* a, const void* b, void* y, int64_t n, int relu, void* stream);
 int shdr_avgpool2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
@@ -464,7 +469,8 @@ int shdr_upsample_zero2_f16(const void* dy, void* dx, int N, int H, int W, int C
 /* tf.reduce_mean(x,[1,2]): fp16 [N,HW,C] -> fp32 [N,C], and its backward (fp32 dy -> fp16 dx) */
 int shdr_gap_fwd_f16(const void* x, float* y, int N, int HW, int C, void* stream);
 int shdr_gap_bwd_f16(const float* dy, void* dx, int N, int HW, int C, void* stream);
-/* training-mode BatchNormalization on fp16 tensors; statistics, parameters and their gradients fp32 (sums in double) */
+/* training-mode BatchNormalization on fp16 tensors; statistics, parameters and their gradients fp32 (sums in double);
+ * ws: shdr_workspace_bytes(SHDR_OP_BATCHNORM, NULL, C) bytes */
 int shdr_bn_stats_f16(const void* x, double* ws, float* mean, float* var, float* moving_mean, float* moving_var, int64_t npix, int C,
                       float momentum, void* stream);
 int shdr_bn_train_apply_f16(const void* x, const float* mean, const float* var, const float* gamma, const float* beta, void* y,

@@ -32,6 +32,8 @@ class ConvDesc(ctypes.Structure):
                 ("prologue", ctypes.c_int32)]
 
 
+OP_CONV2D_FWD, OP_CONV2D_DGRAD, OP_CONV2D_WGRAD_WINOGRAD, OP_BATCHNORM, OP_ACT_BWD_BIAS = 0, 1, 2, 3, 4     # shdr_workspace_bytes(op, ...)
+
 # name -> (restype, argtypes); must list every symbol of include/shdr.h
 SIGNATURES = {
     "shdr_last_error": (ctypes.c_char_p, []),
@@ -48,7 +50,7 @@ SIGNATURES = {
     "shdr_conv2d_winograd_fused_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
     "shdr_conv2d_winograd_fused2_f32": (c_int, [c_ptr] * 8 + [c_int] * 8 + [c_ptr]),
     "shdr_conv2d_winograd_fused_up2_f32": (c_int, [c_ptr] * 6 + [c_int] * 7 + [c_ptr]),
-    "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
+    "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),
     "shdr_crc32c": (ctypes.c_uint32, [c_ptr, ctypes.c_uint64, ctypes.c_uint32]),
@@ -133,7 +135,7 @@ SIGNATURES = {
     "shdr_pad_channels_f32_to_f16": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_pack3_f16": (c_int, [c_ptr] * 4 + [c_int, c_ptr, c_int, c_i64, c_int, c_ptr]),
     "shdr_unpack3_f16": (c_int, [c_ptr] * 5 + [c_int, c_int, c_i64, c_int, c_ptr]),
-    "shdr_act_bwd_bias_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
+    "shdr_act_bwd_bias_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_add_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "shdr_avgpool2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_avgpool2_bwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),

@@ -659,6 +659,11 @@ def bias_grad(dz, out=None):
     return db
 
 
+def _bias_ws(c, device):
+    """one row of partial channel sums per reduction block of act_bwd_bias (sized by the library)"""
+    return torch.empty(int(_lib.load().shdr_workspace_bytes(_lib.OP_ACT_BWD_BIAS, None, int(c))) // 4, device=device, dtype=torch.float32)
+
+
 def act_bwd_bias(dy, y, act, out=None):
     """(dz, db) of y = act(z + bias): dz = dy * act'(y), db = sum over pixels of dz -- one fused pass when the channel
     count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise.  `out`: gradient buffer to accumulate db into."""
@@ -678,7 +683,8 @@ def act_bwd_bias(dy, y, act, out=None):
         y = _chk(_d(y), "y")
         dz = torch.empty_like(dy)
         yp, zp = _ptr(y), _ptr(dz)
-    _lib.check(lib.shdr_act_bwd_bias_f32(_ptr(dy), yp, zp, _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f32")
+    _lib.check(lib.shdr_act_bwd_bias_f32(_ptr(dy), yp, zp, _ptr(db), _ptr(_bias_ws(c, dy.device)), dy.numel() // c, c, act, _stream()),
+               "shdr_act_bwd_bias_f32")
     return dz, db
 
 
@@ -787,7 +793,9 @@ def gap_bwd(dy, x_shape, dtype=torch.float32):
 
 
 def _bn_ws(c, device):
-    return torch.empty(2 * c, device=device, dtype=torch.float64)
+    """workspace of the BatchNorm reductions (sums + one partial row per block), sized by the library"""
+    nbytes = int(_lib.load().shdr_workspace_bytes(_lib.OP_BATCHNORM, None, int(c)))
+    return torch.empty(nbytes // 8, device=device, dtype=torch.float64)
 
 
 def bn_stats(x, moving_mean=None, moving_var=None, momentum=0.99):
@@ -1183,11 +1191,14 @@ def act_bwd_bias_h(dy, y, act, want_db, out=None):
     db = (out if out is not None else torch.zeros(c, device=dy.device, dtype=torch.float32)) if want_db else None
     if act == ACT_NONE:
         if want_db:
-            _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), None, None, _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f16")
+            _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), None, None, _ptr(db), _ptr(_bias_ws(c, dy.device)), dy.numel() // c, c, act,
+                                                 _stream()), "shdr_act_bwd_bias_f16")
         return dy, db
     y = _chkh(_d(y), "y")
     dz = torch.empty_like(dy)
-    _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), dy.numel() // c, c, act, _stream()), "shdr_act_bwd_bias_f16")
+    ws = _bias_ws(c, dy.device) if want_db else None
+    _lib.check(lib.shdr_act_bwd_bias_f16(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), _ptr(ws), dy.numel() // c, c, act, _stream()),
+               "shdr_act_bwd_bias_f16")
     return dz, db
 
 

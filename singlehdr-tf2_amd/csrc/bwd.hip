@@ -52,9 +52,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // Fused dz = dy * act'(y) and db[c] += sum_p dz[p][c]: one pass over dy / y instead of act_bwd + bias_grad (three tensor
 // passes instead of four, float4 accesses).  C / 4 is a power of two <= 256, so a thread's channel quad is fixed over its
 // grid-stride loop and the four sums stay in registers; one LDS tree + one atomic per block and channel.
+// ws != null: every block writes its C sums to row blockIdx.x of ws instead (folded by shdr::col_fold_kernel) -- no atomics on the
+// same C addresses, so the grid can be as large as the stream wants (3.7 -> 5 TB/s).
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           float* __restrict__ dz, float* __restrict__ db, long nquads,
-                                                           int Q, int act) {
+                                                           float* __restrict__ dz, float* __restrict__ db, float* __restrict__ ws,
+                                                           long nquads, int Q, int act) {
   __shared__ float4 part[256];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   auto one = [&](long e, const float4 g, const float4 yv) {
@@ -107,8 +109,12 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
   }
   if ((int)threadIdx.x < Q) {
     const float4 m = part[threadIdx.x];
-    float* o = db + 4 * threadIdx.x;
-    atomicAdd(o, m.x); atomicAdd(o + 1, m.y); atomicAdd(o + 2, m.z); atomicAdd(o + 3, m.w);
+    if (ws) {
+      *reinterpret_cast<float4*>(ws + (size_t)blockIdx.x * 4 * Q + 4 * threadIdx.x) = m;
+    } else {
+      float* o = db + 4 * threadIdx.x;
+      atomicAdd(o, m.x); atomicAdd(o + 1, m.y); atomicAdd(o + 2, m.z); atomicAdd(o + 3, m.w);
+    }
   }
 }
 
@@ -398,16 +404,27 @@ __global__ __launch_bounds__(256) void bn_reduce4_kernel(const float* __restrict
     for (int e = 0; e < 4; ++e) { part[e][threadIdx.x] = s1[e]; part[4 + e][threadIdx.x] = s2[e]; }
     __syncthreads();
     if (pl == 0 && q < Q) {
+      double* wp = ws + (size_t)(1 + blockIdx.x) * 2 * C;       // this block's partial row, summed by bn_fold_kernel: no atomics, no memset
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         double t1 = s1[e], t2 = s2[e];
         for (int j = 1; j < PL; ++j) { t1 += part[e][j * QL + ql]; t2 += part[4 + e][j * QL + ql]; }
-        atomicAdd(ws + 4 * q + e, t1);
-        atomicAdd(ws + C + 4 * q + e, t2);
+        wp[4 * q + e] = t1;
+        wp[C + 4 * q + e] = t2;
       }
     }
     __syncthreads();
   }
+}
+// ws[col] = sum over the g partial rows ws[(1 + b) * 2C + col]: one wave per column, lanes stride over the rows
+__global__ __launch_bounds__(256) void bn_fold_kernel(double* __restrict__ ws, int C, int g) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= 2 * C) return;
+  double t = 0.0;
+  for (int b = lane; b < g; b += 64) t += ws[(size_t)(1 + b) * 2 * C + col];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (lane == 0) ws[col] = t;
 }
 
 // mean/var (biased) from the double sums; optional Keras moving-average update
@@ -789,12 +806,13 @@ inline void launch_bn_reduce(hipStream_t st, const float* a, const float* x, con
     while (QL < Q && QL < 256) QL <<= 1;
     const long PL = 256 / QL;
     long g = (npix + PL * 16 - 1) / (PL * 16);          // >= 16 pixels per thread before the grid is capped
-    // every block ends with 2 fp64 atomics per channel on the SAME addresses: 1024 blocks measured 2x slower than 256 on a
-    // 134 MB tensor (0.111 vs 0.053 ms); the largest tensors want 512
-    const long cap = npix * C >= (1L << 26) ? 512 : 256;
-    g = g < 1 ? 1 : (g > cap ? cap : g);
+    // every block owns a partial row of the workspace (2 fp64 atomics per channel and block on the SAME addresses made 1024 blocks
+    // 2x slower than 256 on a 134 MB tensor; the rows are summed by bn_fold_kernel)
+    g = g < 1 ? 1 : (g > SHDR_BN_MAX_BLOCKS ? SHDR_BN_MAX_BLOCKS : g);
     hipLaunchKernelGGL(bn_reduce4_kernel, dim3((unsigned)g), dim3(256), 0, st, a, x, y, mean, ws, npix, C, mode);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((2 * C + 3) / 4)), dim3(256), 0, st, ws, C, (int)g);
   } else {
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3(reduce_grid(npix, C)), dim3(256), 0, st, a, x, y, mean, ws, npix, C, mode);
   }
 }
@@ -807,7 +825,7 @@ extern "C" int shdr_act_bwd_f32(const float* dy, const float* y, float* dx, int6
   hipLaunchKernelGGL(act_bwd_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, S(stream), dy, y, dx, (long)n, act);
   return shdr::check_launch("act_bwd");
 }
-extern "C" int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, int64_t npix, int C, int act,
+extern "C" int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz, float* db, float* ws, int64_t npix, int C, int act,
                                      void* stream) {
   SHDR_REQUIRE(dy && db, SHDR_E_NULL, "act_bwd_bias: null pointer");
   SHDR_REQUIRE(act == SHDR_ACT_NONE || (y && dz), SHDR_E_NULL, "act_bwd_bias: y and dz are needed with an activation");
@@ -821,9 +839,16 @@ extern "C" int shdr_act_bwd_bias_f32(const float* dy, const float* y, float* dz,
   // <= 512 blocks: every block ends with one atomic per channel on the SAME C addresses (2048 blocks measured slower than
   // the unfused pair)
   int grid = shdr::stream_grid(nquads);
+  if (ws && nquads >= (1L << 22)) {                   // partial rows + fold: the grid of a plain streaming kernel (pays from ~64 MB on)
+    SHDR_REQUIRE(shdr::aligned16(ws), SHDR_E_ALIGN, "act_bwd_bias: ws must be 16-byte aligned");
+    if (grid > shdr::kBiasMaxBlocks) grid = shdr::kBiasMaxBlocks;
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), 0, S(stream), dy, y, dz, db, ws, nquads, Q, act);
+    shdr::launch_col_fold(ws, db, grid, C, S(stream));
+    return shdr::check_launch("act_bwd_bias");
+  }
   const int cap = nquads >= (1L << 24) ? 512 : (nquads >= (1L << 23) ? 384 : 256);     // measured per tensor size
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), 0, S(stream), dy, y, dz, db, nquads, Q, act);
+  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), 0, S(stream), dy, y, dz, db, (float*)nullptr, nquads, Q, act);
   return shdr::check_launch("act_bwd_bias");
 }
 extern "C" int shdr_clip_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, float lo, float hi, void* stream) {
@@ -887,7 +912,6 @@ extern "C" int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float*
   SHDR_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), SHDR_E_NULL, "bn_stats: moving stats come in pairs");
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_stats: bad shape");
   hipStream_t st = S(stream);
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_stats: memset");
   launch_bn_reduce(st, x, nullptr, nullptr, nullptr, ws, (long)npix, C, 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, mean, var, moving_mean, moving_var,
                      (long)npix, C, momentum);
@@ -907,7 +931,6 @@ extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_r
   SHDR_REQUIRE(dy && x && mean && var && gamma && ws && dgamma && dbeta && dx, SHDR_E_NULL, "bn_bwd: null pointer");
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_bwd: bad shape");
   hipStream_t st = S(stream);
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_bwd: memset");
   launch_bn_reduce(st, dy, x, y_relu, mean, ws, (long)npix, C, 1);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, var, dgamma, dbeta, C, eps);
   const int Q = C / 4;

@@ -311,7 +311,8 @@ extern "C" int64_t shdr_workspace_bytes(int op, const shdr_conv2d_desc* d, int a
     case SHDR_OP_CONV2D_FWD: return shdr_conv2d_workspace_bytes_f32(d, arg);
     case SHDR_OP_CONV2D_DGRAD: return shdr_conv2d_dgrad_workspace_bytes_f32(d, arg);
     case SHDR_OP_CONV2D_WGRAD_WINOGRAD: return d ? (int64_t)16 * (arg ? d->C2 : d->C1) * d->Cout * (int64_t)sizeof(float) : -1;
-    case SHDR_OP_BATCHNORM: return arg > 0 ? (int64_t)2 * arg * (int64_t)sizeof(double) : -1;     // arg = channels
+    case SHDR_OP_BATCHNORM: return arg > 0 ? (int64_t)2 * arg * (1 + SHDR_BN_MAX_BLOCKS) * (int64_t)sizeof(double) : -1;     // arg = channels
+    case SHDR_OP_ACT_BWD_BIAS: return arg > 0 ? (int64_t)arg * shdr::kBiasMaxBlocks * (int64_t)sizeof(float) : -1;
     default: return -1;
   }
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void unpack3_h_kernel(const hf* __restrict__ y
 // octet is fixed over its grid-stride loop (the launcher makes gridDim * 256 a multiple of O), partial sums go through LDS
 // atomics, one global atomic per block and channel.
 __global__ __launch_bounds__(256) void act_bwd_bias_h_kernel(const hf* __restrict__ dy, const hf* __restrict__ y, hf* __restrict__ dz,
-                                                             float* __restrict__ db, long nvec, int O, int act) {
+                                                             float* __restrict__ db, float* __restrict__ ws, long nvec, int O, int act) {
   extern __shared__ float sdb[];                              // [8 * O]
   if (db) {
     for (int i = threadIdx.x; i < 8 * O; i += 256) sdb[i] = 0.f;
@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void act_bwd_bias_h_kernel(const hf* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) atomicAdd(&sdb[8 * o + j], s[j]);
     __syncthreads();
-    for (int i = threadIdx.x; i < 8 * O; i += 256) atomicAdd(db + i, sdb[i]);
+    if (ws) {                                                  // this block's partial row (folded by shdr::col_fold_kernel)
+      for (int i = threadIdx.x; i < 8 * O; i += 256) ws[(size_t)blockIdx.x * 8 * O + i] = sdb[i];
+    } else {
+      for (int i = threadIdx.x; i < 8 * O; i += 256) atomicAdd(db + i, sdb[i]);
+    }
   }
 }
 
@@ -483,6 +487,17 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const hf* __restrict__
         run = 0;
       };
       long p = (long)blockIdx.x * PL + pl;
+      if (mode == 0) {
+        for (; p + 7 * step < npix; p += 8 * step) {         // statistics pass: eight 16-byte loads in flight per thread
+          V8 av[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) av[u] = ldh(a + (p + u * step) * C + 8 * o);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc(av[u], av[u], av[u]);
+          run += 8;
+          if (run >= 16) fold();
+        }
+      }
       for (; p + 3 * step < npix; p += 4 * step) {           // four vectors per operand in flight
         V8 av[4], xv[4], yv[4];
 #pragma unroll
@@ -516,16 +531,27 @@ __global__ __launch_bounds__(256) void bn_reduce_h_kernel(const hf* __restrict__
     for (int j = 0; j < 8; ++j) { part[j][threadIdx.x] = s1[j]; part[8 + j][threadIdx.x] = s2[j]; }
     __syncthreads();
     if (pl == 0 && o < O) {
+      double* wp = ws + (size_t)(1 + blockIdx.x) * 2 * C;       // this block's partial row; summed by bn_fold_h_kernel (no atomics, no memset)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         double t1 = s1[j], t2 = s2[j];
         for (int k = 1; k < PL; ++k) { t1 += part[j][k * OL + ol]; t2 += part[8 + j][k * OL + ol]; }
-        atomicAdd(ws + 8 * o + j, t1);
-        atomicAdd(ws + C + 8 * o + j, t2);
+        wp[8 * o + j] = t1;
+        wp[C + 8 * o + j] = t2;
       }
     }
     __syncthreads();
   }
+}
+// ws[col] = sum over the g partial rows ws[(1 + b) * 2C + col]: one wave per column, lanes stride over the rows
+__global__ __launch_bounds__(256) void bn_fold_h_kernel(double* __restrict__ ws, int C, int g) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= 2 * C) return;
+  double t = 0.0;
+  for (int b = lane; b < g; b += 64) t += ws[(size_t)(1 + b) * 2 * C + col];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (lane == 0) ws[col] = t;
 }
 __global__ void bn_finalize_h_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ var,
                                      float* __restrict__ mov_mean, float* __restrict__ mov_var, long npix, int C, float momentum) {
@@ -762,7 +788,7 @@ extern "C" int shdr_unpack3_f16(const void* y, float* o0, float* o1, float* o2, 
                      (long)npix, vgg_preprocess_bwd);
   return shdr::check_launch("unpack3_f16");
 }
-extern "C" int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, float* db, int64_t npix, int C, int act, void* stream) {
+extern "C" int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, float* db, float* ws, int64_t npix, int C, int act, void* stream) {
   SHDR_REQUIRE(dy, SHDR_E_NULL, "act_bwd_bias_f16: null pointer");
   SHDR_REQUIRE(act == SHDR_ACT_NONE || (y && dz), SHDR_E_NULL, "act_bwd_bias_f16: y and dz are needed with an activation");
   SHDR_REQUIRE(npix > 0 && C > 0 && C % 8 == 0 && C <= 4096 && act >= 0 && act <= 3, SHDR_E_SHAPE, "act_bwd_bias_f16: bad arguments (C %% 8 == 0)");
@@ -770,9 +796,13 @@ extern "C" int shdr_act_bwd_bias_f16(const void* dy, const void* y, void* dz, fl
                "act_bwd_bias_f16: tensors must be 16-byte aligned");
   const int O = C / 8;
   const long nvec = (long)npix * O;
-  const int cap = db ? (nvec >= (1L << 23) ? 512 : 256) : 2048;
-  hipLaunchKernelGGL(act_bwd_bias_h_kernel, dim3(octet_grid(nvec, O, cap)), dim3(256), db ? 8 * O * sizeof(float) : 0, S(stream), H_(dy),
-                     H_(y), HM_(dz), db, nvec, O, act);
+  const bool rows = db && ws && nvec >= (1L << 22);   // partial rows + fold instead of atomics on the same C addresses (pays from ~64 MB on)
+  const int cap = db && !rows ? (nvec >= (1L << 23) ? 512 : 256) : 2048;
+  int grid = octet_grid(nvec, O, cap);
+  if (rows && grid > shdr::kBiasMaxBlocks) grid = octet_grid(nvec, O, shdr::kBiasMaxBlocks / 2);       // the rounding up to the octet unit stays below the row count
+  hipLaunchKernelGGL(act_bwd_bias_h_kernel, dim3(grid), dim3(256), db ? 8 * O * sizeof(float) : 0, S(stream), H_(dy),
+                     H_(y), HM_(dz), db, rows ? ws : (float*)nullptr, nvec, O, act);
+  if (rows) shdr::launch_col_fold(ws, db, grid, C, S(stream));
   return shdr::check_launch("act_bwd_bias_f16");
 }
 extern "C" int shdr_add_f16(const void* a, const void* b, void* y, int64_t n, int relu, void* stream) {
@@ -859,9 +889,9 @@ inline void launch_bn_reduce_h(hipStream_t st, HP a, HP x, HP y, const float* me
   while (OL < O && OL < 256) OL <<= 1;
   const long PL = 256 / OL;
   long g = (npix + PL * 16 - 1) / (PL * 16);
-  const long cap = npix * C >= (1L << 26) ? 512 : 256;          // fp64 atomics on the same 2C addresses (bwd.hip)
-  g = g < 1 ? 1 : (g > cap ? cap : g);
+  g = g < 1 ? 1 : (g > SHDR_BN_MAX_BLOCKS ? SHDR_BN_MAX_BLOCKS : g);       // every block owns a partial row of the workspace
   hipLaunchKernelGGL(bn_reduce_h_kernel, dim3((unsigned)g), dim3(256), 0, st, a, x, y, mean, ws, npix, C, mode);
+  hipLaunchKernelGGL(bn_fold_h_kernel, dim3((unsigned)((2 * C + 3) / 4)), dim3(256), 0, st, ws, C, (int)g);
 }
 }  // namespace
 extern "C" int shdr_bn_stats_f16(const void* x, double* ws, float* mean, float* var, float* moving_mean, float* moving_var, int64_t npix,
@@ -870,7 +900,6 @@ extern "C" int shdr_bn_stats_f16(const void* x, double* ws, float* mean, float* 
   SHDR_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), SHDR_E_NULL, "bn_stats_f16: moving stats come in pairs");
   SHDR_REQUIRE(npix > 0 && C > 0 && C % 8 == 0, SHDR_E_SHAPE, "bn_stats_f16: bad shape (C %% 8 == 0)");
   hipStream_t st = S(stream);
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_stats_f16: memset");
   launch_bn_reduce_h(st, H_(x), nullptr, nullptr, nullptr, ws, (long)npix, C, 0);
   hipLaunchKernelGGL(bn_finalize_h_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, mean, var, moving_mean, moving_var, (long)npix, C, momentum);
   return shdr::check_launch("bn_stats_f16");
@@ -889,7 +918,6 @@ extern "C" int shdr_bn_bwd_f16(const void* dy, const void* x, const void* y_relu
   SHDR_REQUIRE(dy && x && mean && var && gamma && ws && dgamma && dbeta && dx, SHDR_E_NULL, "bn_bwd_f16: null pointer");
   SHDR_REQUIRE(npix > 0 && C > 0 && C % 8 == 0, SHDR_E_SHAPE, "bn_bwd_f16: bad shape (C %% 8 == 0)");
   hipStream_t st = S(stream);
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "bn_bwd_f16: memset");
   launch_bn_reduce_h(st, H_(dy), H_(x), H_(y_relu), mean, ws, (long)npix, C, 1);
   hipLaunchKernelGGL(bn_bwd_finalize_h_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, var, dgamma, dbeta, C, eps);
   const long nvec = (long)npix * (C / 8);

@@ -53,6 +53,24 @@ inline int stream_grid(int64_t work_items, int block = 256) {
   return static_cast<int>(g);
 }
 
+// out[c] += sum over the g partial rows ws[b * C + c] (written by reduction kernels that give every block its own row instead
+// of ending in atomics on the same C addresses).  Block = 64 columns x 4 row lanes, blockIdx.y = row slice of <= 256 rows.
+__global__ __launch_bounds__(256) static void col_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int g, int C) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 256, r1 = r0 + 256 < g ? r0 + 256 : g;
+  float t = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) t += ws[(size_t)r * C + c];
+  part[rl][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+inline void launch_col_fold(const float* ws, float* out, int g, int C, hipStream_t st) {
+  hipLaunchKernelGGL(col_fold_kernel, dim3((C + 63) / 64, (g + 255) / 256), dim3(256), 0, st, ws, out, g, C);
+}
+constexpr int kBiasMaxBlocks = 2048;          // rows of the act_bwd_bias workspace (shdr_workspace_bytes(SHDR_OP_ACT_BWD_BIAS))
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case SHDR_ACT_RELU: return fmaxf(v, 0.0f);
