@@ -416,6 +416,27 @@ def add_relu(a, b):
     return AddReluFn.apply(a, b)
 
 
+class ForkFn(torch.autograd.Function):
+    """A fan-out point of the tape: n aliases of x, each for ONE consumer.  autograd would sum the consumers' gradients with its own
+    at::add; here the sum is libshdr's add kernel (fp32 or fp16), so the training step stays free of torch arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_c(g) for g in gs if g is not None]
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = K.add(acc, g)
+        return acc, None
+
+
+def fork(x, n=2):
+    return ForkFn.apply(x, n)
+
+
 # ---------------------------------------------------------------------------
 # inverse-CRF head, CRF application
 # ---------------------------------------------------------------------------

@@ -730,6 +730,14 @@ def add(a, b, relu=False):
     return y
 
 
+def fork(x, n=2):
+    """n aliases of x for n consumers (skip connections, residual shortcuts, multi-term losses): on a gradient tape the consumers'
+    gradients are summed by the add kernel of this library; without a tape it is x itself, n times"""
+    if not _needs_grad(x):
+        return (x,) * n
+    return AUTOGRAD.fork(x, n)
+
+
 def affine_act(x, scale=None, shift=None, residual=None, act=ACT_NONE):
     """act(x * scale[c] + shift[c] + residual) on NHWC"""
     if _needs_grad(x, scale, shift, residual):
@@ -1281,7 +1289,10 @@ def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
         return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, None, None, None, ACT_NONE, ALGO_AUTO, None, None, None, None, 0,
                            True if keep_y else "only")
     y = conv2d(x, w, bias, act1=act1)
-    return (y, maxpool2(y)) if keep_y else maxpool2(y)
+    if not keep_y:
+        return maxpool2(y)
+    ya, yb = fork(y)                   # the skip connection and the pooling both consume y
+    return ya, maxpool2(yb)
 
 
 def conv2d_winograd(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):

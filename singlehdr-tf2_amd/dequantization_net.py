@@ -69,11 +69,11 @@ class _unet(Layer):
             x = self.conv1.call_padded(input_images, cin_pad=cin, act1=K.ACT_LRELU)
         else:
             x = self.conv1(input_images, act1=K.ACT_LRELU)
-        s1 = self.conv2(x, act1=K.ACT_LRELU)
-        s2 = self.d2(s1)
-        s3 = self.d3(s2)
-        s4 = self.d4(s3)
-        x = self.enc(s4)
+        s1, t1 = K.fork(self.conv2(x, act1=K.ACT_LRELU))      # each encoder output feeds the next level and its skip connection
+        s2, t2 = K.fork(self.d2(t1))
+        s3, t3 = K.fork(self.d3(t2))
+        s4, t4 = K.fork(self.d4(t3))
+        x = self.enc(t4)
         x = self.u4(x, s4)
         x = self.u3(x, s3)
         x = self.u2(x, s2)

@@ -112,11 +112,12 @@ class model(Layer):
         train = is_training(training)
         if list(self.VGG_MEAN) != [103.939, 116.779, 123.68]:
             raise NotImplementedError("custom VGG_MEAN is not supported by the HIP preprocess kernel")
+        input_layer, il = K.fork(input_layer)        # the 3-channel BGR image of the last skip layer and the padded encoder input
         bgr = K.vgg_preprocess(input_layer)          # x*255, RGB->BGR, - mean  (:149-153)
         if K.native_fp16() and train:                # BASELINE configs[4]: fp16 feature maps (16 channels: the input gradient of
-            x, d1 = self.d1(K.vgg_preprocess(input_layer, 16, K.HALF))    # the first conv runs on the 16-channel MFMA tile)
+            x, d1 = self.d1(K.vgg_preprocess(il, 16, K.HALF))    # the first conv runs on the 16-channel MFMA tile)
         else:
-            x, d1 = self.d1(K.vgg_preprocess(input_layer, 4))   # same, zero 4th channel: MFMA-friendly
+            x, d1 = self.d1(K.vgg_preprocess(il, 4))   # same, zero 4th channel: MFMA-friendly
         x, d2 = self.d2(x)
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)

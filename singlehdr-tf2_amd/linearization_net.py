@@ -67,8 +67,9 @@ class resBlock_type1(Layer):
 
     def call(self, x, training="training"):
         t = training
+        x, xb = K.fork(x)                  # shortcut branch and bottleneck branch
         norm1 = _conv_bn(self.conv1, self.norm1, x, relu=False, training=t)
-        act2 = _conv_bn(self.conv2, self.norm2, x, relu=True, training=t)
+        act2 = _conv_bn(self.conv2, self.norm2, xb, relu=True, training=t)
         act3 = _conv_bn(self.conv3, self.norm3, act2, relu=True, training=t)
         return _conv_bn(self.conv4, self.norm4, act3, relu=True, residual=norm1, training=t)  # relu(norm1 + norm4)
 
@@ -87,7 +88,8 @@ class resBlock_type2(Layer):
 
     def call(self, x, training="training"):
         t = training
-        act1 = _conv_bn(self.conv1, self.norm1, x, relu=True, training=t)
+        x, xb = K.fork(x)                  # identity shortcut and bottleneck branch
+        act1 = _conv_bn(self.conv1, self.norm1, xb, relu=True, training=t)
         act2 = _conv_bn(self.conv2, self.norm2, act1, relu=True, training=t)
         return _conv_bn(self.conv3, self.norm3, act2, relu=True, residual=x, training=t)  # relu(x + norm3)
 

@@ -228,14 +228,14 @@ class JointTrainStep:
             alpha = K.alpha_mask(clipped_hdr_t, thr)
             bgr_pred_hal = self._hal(clipped_hdr_t, training=True)
             A_pred = K.blend_const(clipped_hdr_t, alpha, bgr_pred_hal, thr)      # clipped + alpha * bgr2rgb(hal)
-            y_final_gamma = K.logc(A_pred)
+            y_final_gamma, y_l1, y_tv = K.fork(K.logc(A_pred), 3)                  # perceptual, L1 and TV terms
             with torch.no_grad():
                 hdr_t_gamma = K.logc(hdr_t)
                 target_feats = self._vgg2(hdr_t_gamma)
             feats = self._vgg(y_final_gamma)
             perceptual_loss = sum(K.diff_loss(fa, fb, 1) for fa, fb in zip(feats, target_feats))
-            l1loss_hal = K.diff_loss(y_final_gamma, hdr_t_gamma, 1)
-            tv_loss = K.tv_loss(y_final_gamma)                                     # batch-global scalar [1]
+            l1loss_hal = K.diff_loss(y_l1, hdr_t_gamma, 1)
+            tv_loss = K.tv_loss(y_tv)                                              # batch-global scalar [1]
             b_glob, msum = _dp_scalars(self, mask)
             # exact sharding of tv_loss * loss_mask: d/dtheta sums to (sum_all mask / G) * sum_r grad tv_r
             tv_w = mask if self.world == 1 else torch.ones_like(mask) * (msum / b_glob)
@@ -367,17 +367,18 @@ class FinetuneStep:
 
     def forward(self, ldr, hdr):
         pred_deq = self._deq(ldr, training=True)
-        C_pred = K.clip(pred_deq, 0.0, 1.0)
+        # the chained predictions fan out (C: lin, apply_rf, ref; B: hal, blend, ref; A: ref): K.fork sums their gradients in libshdr
+        C_pred, c_rf, c_ref = K.fork(K.clip(pred_deq, 0.0, 1.0), 3)
         pred_invcrf = self._lin(C_pred, training=True)
-        B_pred = tf_utils.apply_rf(C_pred, pred_invcrf)
+        B_pred, b_blend, b_ref = K.fork(tf_utils.apply_rf(c_rf, pred_invcrf), 3)
         bgr_hal_res = self._hal(B_pred, training=True)
-        A_pred = K.alpha_blend(B_pred, bgr_hal_res, self.THRESHOLD)      # alpha is a function of B_pred here
+        A_pred = K.alpha_blend(b_blend, bgr_hal_res, self.THRESHOLD)     # alpha is a function of B_pred here
         with torch.no_grad():
             hdr_gamma = K.logc(hdr)
         if self.precision == "fp16":                 # fp16 feature maps: [A, B, C, 0...] on two 16-byte channel groups
-            refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 16, K.HALF), training=True)
+            refinement_output = self._ref(K.pack3([A_pred, b_ref, c_ref], 16, K.HALF), training=True)
         else:
-            refinement_output = self._ref(K.pack3([A_pred, B_pred, C_pred], 12), training=True)
+            refinement_output = self._ref(K.pack3([A_pred, b_ref, c_ref], 12), training=True)
         refinement_output = K.mean_norm(refinement_output, 1e-6, 0.5)
         refinement_output_gamma = K.logc(refinement_output)
         n_per = refinement_output_gamma[0].numel()

@@ -54,7 +54,7 @@ class Vgg16(Layer):
         x = K.vgg_preprocess(rgb, 4)                 # vgg16.py:101-109 (+ zero 4th channel)
         # only the pooled tensors leave the net: without a tape (the target branch of the perceptual loss) the last conv of a
         # block writes MaxPool2D(2)(relu(conv)) straight from the fused Winograd epilogue and never stores the conv output
-        pool1 = self._conv_pool("conv1_2", self._conv("conv1_1", x))
-        pool2 = self._conv_pool("conv2_2", self._conv("conv2_1", pool1))
-        pool3 = self._conv_pool("conv3_3", self._conv("conv3_2", self._conv("conv3_1", pool2)))
+        pool1, p1 = K.fork(self._conv_pool("conv1_2", self._conv("conv1_1", x)))      # a feature of the loss AND the next block's input
+        pool2, p2 = K.fork(self._conv_pool("conv2_2", self._conv("conv2_1", p1)))
+        pool3 = self._conv_pool("conv3_3", self._conv("conv3_2", self._conv("conv3_1", p2)))
         return pool1, pool2, pool3
