@@ -52,6 +52,7 @@ extern "C" {
 #define SHDR_ALGO_MFMA_BF16 5  /* force the MFMA path with bf16 operands                 */
 #define SHDR_ALGO_AUTO_F16  6  /* AUTO; fp16 operands wherever the MFMA path is taken    */
 #define SHDR_ALGO_AUTO_BF16 7  /* AUTO; bf16 operands wherever the MFMA path is taken    */
+#define SHDR_ALGO_AUTO_EXACT 8 /* AUTO without the split-operand fp16 kernels (SHDR_PLAN_X3): every product an fp32 FMA / fp32 MFMA */
 
 const char* shdr_last_error(void);
 /* library / code-object version string, e.g. "libshdr 0.1 gfx950" */
@@ -122,7 +123,9 @@ enum {
   SHDR_PLAN_DIRECT = 0,           /* VALU direct convolution (shapes the MFMA tile cannot take)                       */
   SHDR_PLAN_MFMA = 1,             /* implicit GEMM: LDS-DMA / register-staged / register-A kernel, chosen by shape    */
   SHDR_PLAN_WINOGRAD_FUSED = 2,   /* one-kernel Winograd F(2x2,3x3) (3x3 stride 1 SAME, Cin % 8 == 0, Cout % 64 == 0) */
-  SHDR_PLAN_WINOGRAD_PLANES = 3   /* three-kernel Winograd for wide layers whose Cout is not a multiple of 64         */
+  SHDR_PLAN_WINOGRAD_PLANES = 3,  /* three-kernel Winograd for wide layers whose Cout is not a multiple of 64         */
+  SHDR_PLAN_X3 = 4                /* 3x3 stride 1, C % 32 == 0 per source, Cout % 64 == 0, enough tiles to fill the chip: fp32 operands split
+                                     into two fp16 terms, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation (conv_x3.hip) */
 };
 int shdr_conv2d_plan_f32(const shdr_conv2d_desc* d, int has_residual);
 /* The prepared form of the HWIO filter `w` for that plan: the packed Winograd transform U = G g G^T, or the plain filter with
@@ -365,6 +368,17 @@ int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, const float
 int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const float* bias, const float* scale,
                                        const float* shift, float* y, int N, int H, int W, int Cin, int Cout,
                                        int act1, int act2, void* stream);
+
+/* fp32 3x3 / stride-1 / SAME convolution on the fp16 matrix pipe (SHDR_PLAN_X3; csrc/conv_x3.hip): x = xh + xl 2^-11, w 2^S = wh + wl in
+ * fp16, x w = xh wh + xl (wh 2^-11) + xh wl accumulated in fp32 -- 3 * 2^-22 relative per product, the level of fp32 rounding itself.
+ * Needs C1 % 32 == 0, C2 % 32 == 0, Cout % 64 == 0, |x| < 65504.  prepared: shdr_conv2d_x3_filter_elems_f32 floats, written by
+ * shdr_conv2d_x3_prepare_filter_f32 (the skip scale of the second source folded in).  y = act2(affine(act1(conv + bias))).
+ * Same call sites as shdr_conv2d_winograd_fused2_f32; reached through shdr_conv2d_fwd_prepared_f32 / shdr_conv2d_dgrad_f32. */
+int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d);
+int64_t shdr_conv2d_x3_filter_elems_f32(int Ct, int Cout);
+int shdr_conv2d_x3_prepare_filter_f32(const float* w, float* prepared, int C1, int C2, int Cout, float x2_scale, void* stream);
+int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                           const float* scale, const float* shift, float* y, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

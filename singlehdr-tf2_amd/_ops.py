@@ -29,6 +29,12 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 PROLOGUE_NONE, PROLOGUE_BILINEAR2X = 0, 1      # shdr_conv2d_desc.prologue
 ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
+ALGO_AUTO_EXACT = 8    # AUTO without the split-operand fp16 kernel (plan "x3"): every product an fp32 FMA / fp32 MFMA
+EXACT_FP32 = False     # True: ask the library for ALGO_AUTO_EXACT wherever this module would ask for ALGO_AUTO
+
+
+def _auto(algo):
+    return ALGO_AUTO_EXACT if (algo == ALGO_AUTO and EXACT_FP32) else algo
 
 # Precision of the conv path.
 #   "fp32"  : the parity path (exact-fp32 MFMA, Winograd where it pays).
@@ -196,7 +202,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     d.pad_t, d.pad_l, d.Ho, d.Wo = pt, pl, ho, wo
     d.x2_scale = float(x2_scale)
     d.act1, d.act2 = act1, act2
-    d.algo = algo
+    d.algo = _auto(algo)
     d.w_batch_stride = int(w_batch_stride)
     d.prologue = int(prologue)
     res_cs = 0
@@ -269,7 +275,7 @@ def _prepared_filter(lib, w, d, has_res):
     return prepared
 
 
-_PLAN_NAMES = {0: "direct", 1: "mfma", 2: "fused", 3: "planes"}
+_PLAN_NAMES = {0: "direct", 1: "mfma", 2: "fused", 3: "planes", 4: "x3"}
 
 
 def conv2d_plan(x_shape, w_shape, c2=0, stride=1, x2_scale=1.0, has_residual=False, cout_valid=None):
@@ -285,7 +291,7 @@ def conv2d_plan(x_shape, w_shape, c2=0, stride=1, x2_scale=1.0, has_residual=Fal
     d.Ho, d.pad_t = same_pad(h, kh, stride)
     d.Wo, d.pad_l = same_pad(wd, kw, stride)
     d.x2_scale = float(x2_scale)
-    d.algo = ALGO_AUTO if WINOGRAD else ALGO_MFMA
+    d.algo = _auto(ALGO_AUTO) if WINOGRAD else ALGO_MFMA
     return _PLAN_NAMES[int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), int(has_residual)))]
 
 
@@ -312,7 +318,7 @@ def conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
     d.Ho, d.pad_t = same_pad(h, kh, stride)
     d.Wo, d.pad_l = same_pad(wd, kw, stride)
     d.x2_scale = float(x2_scale)
-    d.algo = _AUTO_ALGO[PRECISION] if WINOGRAD or PRECISION != "fp32" else ALGO_MFMA
+    d.algo = _auto(_AUTO_ALGO[PRECISION]) if WINOGRAD or PRECISION != "fp32" else ALGO_MFMA
     if tuple(dz.shape[:3]) != (n, d.Ho, d.Wo) or dz.shape[3] > cout:
         raise ValueError("conv2d_dgrad: dz shape %s does not match the forward output" % (tuple(dz.shape),))
     nws = int(lib.shdr_conv2d_dgrad_workspace_bytes_f32(ctypes.byref(d), int(which)))

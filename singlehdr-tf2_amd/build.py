@@ -21,6 +21,7 @@ SOURCES = {
     "api.cpp": [],
     "conv.hip": [],
     "conv_plan.hip": [],
+    "conv_x3.hip": [],
     "conv_f16.hip": [],
     "conv_f16_patch.hip": [],
     "conv_f16_w3.hip": [],

@@ -1095,7 +1095,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
                        (!bias || shdr::aligned16(bias)) && (!scale || shdr::aligned16(scale)) &&
                        (!shift || shdr::aligned16(shift)) && (!residual || shdr::aligned16(residual));
   int algo = d->algo;
-  if (algo == SHDR_ALGO_AUTO) algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
+  if (algo == SHDR_ALGO_AUTO || algo == SHDR_ALGO_AUTO_EXACT) algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;
   if (algo == SHDR_ALGO_AUTO_F16 || algo == SHDR_ALGO_AUTO_BF16) {   // reduced-precision operands where the MFMA path applies
     a.prec = (mfma_ok && a.x2_scale == 1.0f) ? (algo == SHDR_ALGO_AUTO_F16 ? 1 : 2) : 0;
     algo = mfma_ok ? SHDR_ALGO_MFMA : SHDR_ALGO_DIRECT;

@@ -19,11 +19,13 @@ inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // the Winograd form a 3x3 / stride-1 / SAME layer takes (measured on MI355X, tools/wino_bench.py): the one-kernel fused form beats
 // the direct kernels on every shape it accepts; the three-kernel "planes" form pays from 128 -> 256 / 256 -> 128 channels up
+inline bool is_auto(int algo) { return algo == SHDR_ALGO_AUTO || algo == SHDR_ALGO_AUTO_EXACT; }
+
 int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   const int Ct = d->C1 + d->C2;
   const int cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   const bool mfma_ok = d->C1 % 4 == 0 && d->C2 % 4 == 0 && d->Cout % 16 == 0;
-  if (d->algo != SHDR_ALGO_AUTO) return d->algo == SHDR_ALGO_DIRECT ? SHDR_PLAN_DIRECT : SHDR_PLAN_MFMA;
+  if (!is_auto(d->algo)) return d->algo == SHDR_ALGO_DIRECT ? SHDR_PLAN_DIRECT : SHDR_PLAN_MFMA;
   int pt = 0, pl = 0, ho = 0, wo = 0;
   shdr_same_pad(d->H, d->KH, d->stride, &ho, &pt);
   shdr_same_pad(d->W, d->KW, d->stride, &wo, &pl);
@@ -31,6 +33,8 @@ int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   const bool wino_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && same && !has_residual && cout_valid == d->Cout &&
                           d->w_batch_stride == 0 && d->y_pix_stride <= 1 && getenv("SHDR_NO_WINOGRAD") == nullptr;
   if (wino_shape) {
+    // the split-operand fp16 kernel first (2-3x the fused Winograd kernel's rate, same accuracy class); SHDR_ALGO_AUTO_EXACT opts out
+    if (d->algo == SHDR_ALGO_AUTO && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
     const bool two_ok = d->C2 == 0 || (d->C2 == d->C1 && d->C1 % 8 == 0 && d->x2_scale == 1.0f);
     if (two_ok && Ct % 8 == 0 && d->Cout % 64 == 0 && Ct >= 32 && (long)d->N * d->H * d->W * Ct < (1L << 32)) return SHDR_PLAN_WINOGRAD_FUSED;
     if (d->C2 == 0 && Ct % 32 == 0 && d->Cout % 16 == 0 && (Ct < d->Cout ? Ct : d->Cout) >= 128 && (long)Ct * d->Cout >= 32768)
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void subfilter_kernel(const float* __restrict_
 
 struct DgradGeom {
   int c_begin, c_count, cout_real, CZ, CC;      // CZ: dz channels the conv reads (multiple of 4), CC: conv output channels (padded to 16 when narrow)
-  bool pad_dz, wino;
+  bool pad_dz, wino, x3;
   size_t off_wt, off_u, off_dz, off_sub, total;
 };
 
@@ -93,12 +97,22 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
   g.pad_dz = g.CZ != g.cout_real;
   g.CC = g.c_count % 16 == 0 ? g.c_count : (g.c_count + 15) / 16 * 16;
   // stride-1 3x3 layers take the fused Winograd kernel when the transposed shape qualifies (the rule of plan_of)
-  g.wino = d->algo == SHDR_ALGO_AUTO && d->stride == 1 && d->KH == 3 && d->KW == 3 && !g.pad_dz && g.CC == g.c_count && g.CZ % 8 == 0 && g.CC % 64 == 0 && g.CZ >= 32 &&
+  g.wino = is_auto(d->algo) && d->stride == 1 && d->KH == 3 && d->KW == 3 && !g.pad_dz && g.CC == g.c_count && g.CZ % 8 == 0 && g.CC % 64 == 0 && g.CZ >= 32 &&
            (long)d->N * d->Ho * d->Wo * g.CZ < (1L << 32) && getenv("SHDR_NO_WINOGRAD") == nullptr;
+  // ... and the split-operand fp16 kernel before it, by the rule of plan_of on the transposed convolution
+  g.x3 = false;
+  if (g.wino && d->algo == SHDR_ALGO_AUTO && g.CZ % 32 == 0) {
+    shdr_conv2d_desc t{};
+    t.N = d->N; t.H = d->Ho; t.W = d->Wo; t.C1 = g.CZ; t.Cout = g.CC; t.KH = 3; t.KW = 3; t.stride = 1; t.pad_t = 2 - d->pad_t; t.pad_l = 2 - d->pad_l;
+    t.Ho = d->H; t.Wo = d->W; t.cout_valid = g.CC;
+    g.x3 = shdr_conv2d_x3_ok_f32(&t) != 0;
+  }
   const size_t filt = (size_t)d->KH * d->KW * g.CZ * g.CC * sizeof(float);
   size_t o = 0;
   g.off_wt = o; o += up256(filt);
-  g.off_u = o; if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
+  g.off_u = o;
+  if (g.x3) o += up256((size_t)shdr_conv2d_x3_filter_elems_f32(g.CZ, g.CC) * sizeof(float));
+  else if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
   g.off_dz = o; if (g.pad_dz) o += up256((size_t)d->N * d->Ho * d->Wo * g.CZ * sizeof(float));
   g.off_sub = o; if (d->stride == 2 && !(d->KH == 1 && d->KW == 1)) o += up256(filt);
   g.total = o;
@@ -124,6 +138,7 @@ extern "C" int64_t shdr_conv2d_prepared_filter_elems_f32(const shdr_conv2d_desc*
   if (!d) return -1;
   const int plan = plan_of(d, has_residual != 0);
   const int64_t Ct = d->C1 + d->C2;
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_filter_elems_f32((int)Ct, d->Cout);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_WINOGRAD_PLANES) return 16 * Ct * d->Cout;
   return (int64_t)d->KH * d->KW * Ct * d->Cout;
 }
@@ -132,6 +147,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
   SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "prepare_filter: null pointer");
   const int plan = plan_of(d, has_residual != 0);
   const int Ct = d->C1 + d->C2;
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_prepare_filter_f32(w, prepared, d->C1, d->C2, d->Cout, d->C2 > 0 ? d->x2_scale : 1.0f, stream);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED) return shdr_winograd_filter_packed_f32(w, prepared, Ct, d->Cout, stream);
   if (plan == SHDR_PLAN_WINOGRAD_PLANES) return shdr_winograd_filter_f32(w, prepared, Ct, d->Cout, stream);
   const long total = (long)d->KH * d->KW * Ct * d->Cout;
@@ -188,7 +204,9 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
                                            d->act2, stream);
   SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd path");
   int rc;
-  if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
+  if (plan == SHDR_PLAN_X3) {
+    rc = shdr_conv2d_fwd_x3_f32(d, x1, x2, prepared, bias, scale, shift, y, stream);
+  } else if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
     SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
     const int Cin = d->C1;
     const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);
@@ -204,7 +222,7 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   } else {
     shdr_conv2d_desc g = *d;
     g.x2_scale = 1.0f;                                   // folded into the prepared filter
-    if (plan == SHDR_PLAN_DIRECT) g.x2_scale = 1.0f;
+    if (g.algo == SHDR_ALGO_AUTO_EXACT) g.algo = SHDR_ALGO_AUTO;
     rc = shdr_conv2d_fwd_f32(&g, x1, x2, prepared, bias, scale, shift, residual, y, stream);
   }
   if (rc) return rc;
@@ -248,6 +266,12 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
   c.cout_valid = g.c_count; c.algo = d->algo;             // (the reduced-precision operand modes carry over to the gradient convs)
   if (d->stride == 1) {
     c.KH = d->KH; c.KW = d->KW; c.pad_t = (d->KH - 1) - d->pad_t; c.pad_l = (d->KW - 1) - d->pad_l; c.Ho = d->H; c.Wo = d->W;
+    if (g.x3) {
+      float* u = reinterpret_cast<float*>(ws + g.off_u);
+      if (int rc = shdr_conv2d_x3_prepare_filter_f32(wt, u, g.CZ, 0, g.CC, 1.0f, stream)) return rc;
+      c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
+      return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, stream);
+    }
     if (g.wino) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       if (int rc = shdr_winograd_filter_packed_f32(wt, u, g.CZ, g.CC, stream)) return rc;

@@ -1,0 +1,324 @@
+// fp32 3x3 / stride-1 convolution on the fp16 matrix pipe: every fp32 operand is split into two fp16 terms and a product is the sum of
+// three v_mfma_f32_16x16x32_f16 (fp32 accumulation) -- "x3".  Replaces the same tf.keras.layers.Conv2D call sites as the fused
+// Winograd kernel (hallucination_net.py:43-75,115-144, dequantization_net.py:35-46, refinement_net.py, vgg16.py:72-83: the 3x3
+// layers with a multiple of 32 input channels per source and a multiple of 64 output channels), forward and input gradient.
+//
+// Arithmetic.  x = xh + xl * 2^-11 with xh = fp16(x), xl = fp16((x - xh) * 2^11): 22 mantissa bits, no underflow of the low term
+// (it is stored scaled).  w' = w * 2^S (S per layer: max |w'| in [2^13, 2^14), so the low term of a weight is a normal fp16 number
+// down to |w| = max |w| * 2^-17) = wh + wl.  Then
+//     x * w' = xh * wh + xl * (wh * 2^-11) + xh * wl + (dropped: xl * wl * 2^-11, < 2^-22 |x w'|)
+// i.e. three MFMAs with the filter images wh, wh * 2^-11 (exact: a power-of-two scaling) and wl, all into ONE fp32 accumulator; the
+// epilogue multiplies by 2^-S (exact).  Per-product error <= 3 * 2^-22 = 7e-7 relative, of random sign -- the level of the fp32
+// rounding of a K >= 288 dot product itself; measured against the float64 oracle in tests/test_gpu_ops.py (same 1e-5 bar as the
+// exact-fp32 kernels, errors reported next to the Winograd kernel's).  |x| must stay below 65504 (fp16 range): activations of
+// these nets are O(1) ... O(1e3); larger values give inf / nan, loudly.
+//
+// Kernel (the layout of conv_f16_w3.hip with fp32 tensors in HBM): block = 16 x 16 pixels x 64 couts, 4 waves; per 32-channel chunk
+// the raw 18 x 18 fp32 patch is loaded ONCE into registers (coalesced 128-byte lines, issued under the MFMAs of the previous
+// chunk), split, and written as two fp16 images of 64-byte rows (16-byte slot XOR-swizzled: conflict-free ds_read_b128); the three
+// filter images stream through LDS per tap (12 KB, register-staged one tap ahead, double-buffered).  Per tap and wave: 16 operand
+// reads feed 48 MFMAs.  66 KB of LDS, two blocks per CU.
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+#include "shdr_internal.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int X3_HEADER_FLOATS = 16;                           // [0] max |w| (bits), [1] 2^-S; 64 bytes keep the images 16-byte aligned
+constexpr int PWID = 18, PPIX = PWID * PWID;                   // raw patch of a 16 x 16 tile
+constexpr int PJ = (PPIX * 8 + 255) / 256;                     // float4 pieces per thread and chunk (11)
+constexpr int PATCH_HALVES = PPIX * 32;                        // one fp16 image of the patch
+constexpr int BN = 64, NT = 4, MT = 4;
+constexpr int IMG_HALVES = BN * 32;                            // one filter image of a tap: [64 couts][32 channels]
+constexpr int UNIT_HALVES = 3 * IMG_HALVES;                    // wh, wh * 2^-11, wl
+constexpr int X3_LDS_BYTES = (2 * PATCH_HALVES + 2 * UNIT_HALVES) * 2;
+
+struct X3Args {
+  const float* x1;
+  const float* x2;
+  const _Float16* wp;      // packed [Cout / 64][units = Ct / 32 * 9][3 images][64][32]
+  const float* hdr;        // packed header: hdr[1] = 2^-S
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* y;
+  int N, H, W, C1, C2, Cout, tiles_x, tiles_y, nblk_m, nblk_n, act1, act2;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+__host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }
+
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 xsm[];
+  _Float16* patch_h = xsm;                                     // [PATCH_HALVES]
+  _Float16* patch_l = xsm + PATCH_HALVES;
+  _Float16* filt = xsm + 2 * PATCH_HALVES;                     // [2][UNIT_HALVES]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
+  const int pn = L % a.nblk_n;
+  int pm = L / a.nblk_n;
+  const int tx = pm % a.tiles_x;
+  pm /= a.tiles_x;
+  const int ty = pm % a.tiles_y;
+  const int img = pm / a.tiles_y;
+  const int n0 = pn * BN, oh0 = ty * 16, ow0 = tx * 16;
+
+  // ---- patch geometry (fixed per block): piece p = tid + 256 j -> (patch pixel, float4 of the 32-channel chunk) ----------------
+  int ppix[PJ];                                                // pixel index in the image tensor, -1: padding / beyond the patch
+  int pdst[PJ];                                                // half offset of the 8-byte destination inside an image
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) {
+    const int p = tid + 256 * j;
+    const int pix = p >> 3, q = p & 7;
+    const int py = pix / PWID, px = pix - py * PWID;
+    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+    const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    ppix[j] = ok ? (img * a.H + ih) * a.W + iw : -1;
+    pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1) : -1;
+  }
+  const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
+  const int nunits = nch * 9;
+  f32x4 pr[PJ];
+  auto load_patch = [&](int c) {                               // chunk c -> registers
+    const bool second = c >= nch1;
+    const float* src = second ? a.x2 : a.x1;
+    const int Cs = second ? a.C2 : a.C1;
+    const int c0 = (second ? c - nch1 : c) << 5;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      const int q = (tid + 256 * j) & 7;
+      pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ppix[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)ppix[j] * (unsigned)Cs + c0 + 4 * q);
+    }
+  };
+  auto store_patch = [&]() {                                   // registers -> the two fp16 images
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      if (pdst[j] < 0) continue;
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = pr[j][e];
+        h[e] = (_Float16)v;
+        l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
+      }
+      *reinterpret_cast<f16x4*>(patch_h + pdst[j]) = h;
+      *reinterpret_cast<f16x4*>(patch_l + pdst[j]) = l;
+    }
+  };
+  // ---- filter units: 12 KB per tap = 768 pieces of 16 bytes, three per thread ---------------------------------------------------
+  const _Float16* wbase = a.wp + (size_t)pn * nunits * UNIT_HALVES;
+  int fdst[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int p = tid + 256 * j;
+    const int im = p >> 8, co = (p & 255) >> 2, slot = p & 3;
+    fdst[j] = im * IMG_HALVES + co * 32 + 8 * (slot ^ f4(co));
+  }
+  u32x4 fr[3];
+  auto load_filt = [&](int u) {
+    const u32x4* g = reinterpret_cast<const u32x4*>(wbase + (size_t)u * UNIT_HALVES);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fr[j] = g[tid + 256 * j];
+  };
+  auto store_filt = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(filt + buf * UNIT_HALVES + fdst[j]) = fr[j];
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fg = lane >> 4;
+  int pix0[MT], b_rd[NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) pix0[mi] = (wave * MT + mi) * PWID + fi;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int row = ni * 16 + fi;
+    b_rd[ni] = row * 32 + 8 * (fg ^ f4(row));
+  }
+
+  load_patch(0);
+  load_filt(0);
+  store_patch();
+  store_filt(0);
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load_patch(c + 1);                        // lands under the nine taps of this chunk
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int u = c * 9 + tap;
+      __syncthreads();                                         // unit u (and, at tap 0, the patch) is in LDS; buffer (u + 1) & 1 is free
+      if (u + 1 < nunits) load_filt(u + 1);
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const _Float16* F = filt + (u & 1) * UNIT_HALVES;
+      f16x8 wh[NT], ws[NT], wl[NT], ph[MT], pl[MT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        wh[ni] = *reinterpret_cast<const f16x8*>(F + b_rd[ni]);
+        ws[ni] = *reinterpret_cast<const f16x8*>(F + IMG_HALVES + b_rd[ni]);
+        wl[ni] = *reinterpret_cast<const f16x8*>(F + 2 * IMG_HALVES + b_rd[ni]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int pix = pix0[mi] + kh * PWID + kw;
+        const int o = pix * 32 + 8 * (fg ^ f4(pix));
+        ph[mi] = *reinterpret_cast<const f16x8*>(patch_h + o);
+        pl[mi] = *reinterpret_cast<const f16x8*>(patch_l + o);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ph[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[ni], pl[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ph[mi], acc[mi][ni], 0, 0, 0);
+        }
+      if (u + 1 < nunits) store_filt((u + 1) & 1);             // read after the next barrier
+    }
+    if (c + 1 < nch) {
+      __syncthreads();                                         // every wave has read the last tap of this chunk's patch
+      store_patch();                                           // visible after the barrier at the top of the next tap loop
+    }
+  }
+
+  // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts) ------------------
+  const float inv_s = a.hdr[1];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int oh = oh0 + wave * MT + mi, ow = ow0 + fi;
+    if (oh >= a.H || ow >= a.W) continue;
+    float* yp = a.y + ((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + n0;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int cl = ni * 16 + 4 * fg;
+      f32x4 v = acc[mi][ni] * inv_s;
+      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + cl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
+      if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + n0 + cl) + *reinterpret_cast<const f32x4*>(a.shift + n0 + cl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
+      *reinterpret_cast<f32x4*>(yp + cl) = v;
+    }
+  }
+}
+
+// ---- filter preparation ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bit patterns
+}
+// packed[nb][u = chunk * 9 + tap][image][co][k]: w * x2-scale * 2^S split into wh, wh * 2^-11, wl
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int Ct,
+                                                      int C1, int Cout, float x2_scale) {
+  const float mx = fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[0]) * fmaxf(1.0f, fabsf(x2_scale)), 1e-30f);
+  int ex;
+  frexpf(mx, &ex);                                             // mx = f * 2^ex, f in [0.5, 1)
+  int S = 14 - ex;                                             // max |w'| in [2^13, 2^14)
+  S = S < -100 ? -100 : (S > 100 ? 100 : S);
+  const float s = ldexpf(1.0f, S);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
+  const int nunits = (Ct >> 5) * 9;
+  const long total = (long)(Cout / 64) * nunits * 64 * 32;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int k = (int)(e & 31), co = (int)((e >> 5) & 63);
+    const long t = e >> 11;
+    const int u = (int)(t % nunits), nb = (int)(t / nunits);
+    const int chunk = u / 9, tap = u - 9 * chunk;
+    const int ch = chunk * 32 + k;
+    float v = w[((size_t)tap * Ct + ch) * Cout + nb * 64 + co] * s;
+    if (ch >= C1) v *= x2_scale;
+    const _Float16 h = (_Float16)v;
+    _Float16* o = out + ((size_t)(nb * nunits + u) * 3) * IMG_HALVES + co * 32 + k;
+    o[0] = h;
+    o[IMG_HALVES] = (_Float16)((float)h * (1.0f / 2048.0f));
+    o[2 * IMG_HALVES] = (_Float16)(v - (float)h);
+  }
+}
+
+}  // namespace
+
+extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
+  if (!d || d->stride != 1 || d->KH != 3 || d->KW != 3 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
+  if (d->C1 % 32 || d->C2 % 32 || d->Cout % 64 || d->C1 <= 0) return 0;
+  const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  if (cv != d->Cout || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
+  if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
+  if (getenv("SHDR_NO_X3")) return 0;
+  // enough blocks to fill the chip: the deepest, smallest maps stay on the fused Winograd kernel (8 x 16 tiles)
+  const long blocks = (long)d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16) * (d->Cout / 64);
+  long min_blocks = 384;
+  if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
+  return blocks >= min_blocks ? 1 : 0;
+}
+
+extern "C" int64_t shdr_conv2d_x3_filter_elems_f32(int Ct, int Cout) {
+  if (Ct <= 0 || Cout <= 0 || Ct % 32 || Cout % 64) return -1;
+  return X3_HEADER_FLOATS + ((int64_t)3 * 9 * Ct * Cout) / 2;      // header + three fp16 images, in floats
+}
+
+extern "C" int shdr_conv2d_x3_prepare_filter_f32(const float* w, float* prepared, int C1, int C2, int Cout, float x2_scale, void* stream) {
+  SHDR_REQUIRE(w && prepared, SHDR_E_NULL, "conv2d_x3_prepare_filter: null pointer");
+  const int Ct = C1 + C2;
+  SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && C1 % 32 == 0 && Cout > 0 && Cout % 64 == 0, SHDR_E_SHAPE, "conv2d_x3_prepare_filter: need C %% 32 == 0, Cout %% 64 == 0");
+  SHDR_REQUIRE(shdr::aligned16(prepared), SHDR_E_ALIGN, "conv2d_x3_prepare_filter: prepared must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(prepared, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
+  const long n = 9L * Ct * Cout;
+  hipLaunchKernelGGL(x3_absmax_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, st, w, n, reinterpret_cast<unsigned*>(prepared));
+  hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, st, w, prepared,
+                     reinterpret_cast<_Float16*>(prepared + X3_HEADER_FLOATS), Ct, C1, Cout, x2_scale);
+  return shdr::check_launch("conv2d_x3_prepare_filter");
+}
+
+extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                      const float* scale, const float* shift, float* y, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && y, SHDR_E_NULL, "conv2d_x3: null desc/x1/filter/y");
+  SHDR_REQUIRE(shdr_conv2d_x3_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3: layer shape not taken by this kernel");
+  SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3: x2 must be given iff C2 > 0");
+  SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3: scale and shift come together");
+  SHDR_REQUIRE(shdr::aligned16(x1) && (!x2 || shdr::aligned16(x2)) && shdr::aligned16(prepared) && shdr::aligned16(y) &&
+                   (!bias || shdr::aligned16(bias)) && (!scale || (shdr::aligned16(scale) && shdr::aligned16(shift))),
+               SHDR_E_ALIGN, "conv2d_x3: tensors must be 16-byte aligned");
+  X3Args a{};
+  a.x1 = x1; a.x2 = x2 ? x2 : x1;
+  a.hdr = prepared;
+  a.wp = reinterpret_cast<const _Float16*>(prepared + X3_HEADER_FLOATS);
+  a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1; a.C2 = d->C2; a.Cout = d->Cout;
+  a.tiles_x = (d->W + 15) / 16;
+  a.tiles_y = (d->H + 15) / 16;
+  a.nblk_m = a.N * a.tiles_x * a.tiles_y;
+  a.nblk_n = a.Cout / 64;
+  a.act1 = d->act1; a.act2 = d->act2;
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done[dev_slot] = true;
+  }
+  const long nblk = (long)a.nblk_m * a.nblk_n;
+  if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
+  hipLaunchKernelGGL(conv_x3_kernel, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+  return shdr::check_launch("conv_x3_kernel");
+}

@@ -106,7 +106,8 @@ def test_planned_call_costs_what_the_fused_kernel_costs(lib):
     g = torch.Generator().manual_seed(1)
     xd = torch.randn((n, h, w, c), generator=g).cuda()
     wd = (torch.randn((3, 3, c, c), generator=g) / (9 * c) ** 0.5).cuda()
-    d = same_desc(lib, n, h, w, c, 0, c, 3, 1, act1=1)
+    d = same_desc(lib, n, h, w, c, 0, c, 3, 1, act1=1, algo=8)          # SHDR_ALGO_AUTO_EXACT: the exact-fp32 plan of this layer
+    assert lib.shdr_conv2d_plan_f32(ctypes.byref(d), 0) == 2            # SHDR_PLAN_WINOGRAD_FUSED
     prepared = torch.empty(lib.shdr_conv2d_prepared_filter_elems_f32(ctypes.byref(d), 0), device="cuda")
     check(lib, lib.shdr_conv2d_prepare_filter_f32(ctypes.byref(d), 0, ptr(wd), ptr(prepared), stream()))
     y = torch.empty((n, h, w, c), device="cuda")
@@ -132,6 +133,18 @@ def test_planned_call_costs_what_the_fused_kernel_costs(lib):
     assert t_planned <= 1.05 * t_raw + 0.02, (t_planned, t_raw)
     tflops = 2.0 * n * h * w * c * c * 9 / (t_planned * 1e-3) / 1e12
     assert tflops >= 150.0, tflops            # direct-form FLOPs: far above what the direct kernel reaches (~125)
+    # SHDR_ALGO_AUTO plans the split-operand fp16 kernel for this layer: same call sequence, fp32-level result, faster again
+    y_exact = y.clone()
+    dx = same_desc(lib, n, h, w, c, 0, c, 3, 1, act1=1)
+    assert lib.shdr_conv2d_plan_f32(ctypes.byref(dx), 0) == 4           # SHDR_PLAN_X3
+    px = torch.empty(lib.shdr_conv2d_prepared_filter_elems_f32(ctypes.byref(dx), 0), device="cuda")
+    check(lib, lib.shdr_conv2d_prepare_filter_f32(ctypes.byref(dx), 0, ptr(wd), ptr(px), stream()))
+
+    def planned_x3():
+        check(lib, lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(dx), ptr(xd), None, ptr(px), None, None, None, None, ptr(y), None, None, stream()))
+    t_x3 = timeit(planned_x3)
+    assert float((y - y_exact).abs().max()) <= 2e-5 * float(y_exact.abs().max())
+    assert t_x3 <= t_planned, (t_x3, t_planned)
 
 
 DGRAD_CASES = [

@@ -359,6 +359,66 @@ def test_conv2d_up2_fused_parity(shdr, shape):
     assert (K.conv2d_plan((n, 2 * h, 2 * w, cin), wt.shape) == "fused") == fused
 
 
+X3_CASES = [(2, 64, 96, 32, 0, 64), (1, 128, 128, 64, 0, 128), (1, 100, 140, 64, 64, 64), (4, 64, 64, 96, 0, 192), (1, 80, 80, 512, 0, 256),
+            (1, 96, 96, 32, 32, 64)]
+
+
+@pytest.mark.parametrize("shape", X3_CASES, ids=["%dx%dx%d_%d+%d_%d" % c for c in X3_CASES])
+def test_conv2d_x3_split_fp16_kernel_is_fp32_accurate(shdr, shape, monkeypatch):
+    """SHDR_PLAN_X3 (csrc/conv_x3.hip): fp32 3x3 convolution as three fp16 MFMA products of split operands.  Held to the SAME bar
+    against the float64 oracle as the exact-fp32 kernels (TOL = 1e-5 of the tensor scale) -- with unit-scale, 1e-3-scale and
+    1e+3-scale activations (the low term of an operand is stored scaled, the weights are scaled per layer: neither underflows) --
+    and compared with what the exact-fp32 path (ALGO_AUTO_EXACT: fused Winograd) reaches on the same input.  Ragged tiles, two
+    sources with a skip scale, the fused epilogue."""
+    n, h, w, c1, c2, cout = shape
+    rng = np.random.default_rng(sum(shape) + 7)
+    K = shdr._ops
+    wt = f32(rng.normal(size=(3, 3, c1 + c2, cout)) / np.sqrt(9 * (c1 + c2)))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=1.0 / 255 if c2 else 1.0) == "x3"
+    for mag in (1.0, 1e-3, 1e3):
+        x = f32(rng.normal(size=(n, h, w, c1)) * mag)
+        x2 = f32(rng.normal(size=(n, h, w, c2)) * 255.0 * mag) if c2 else None
+        x2s = 1.0 / 255 if c2 else 1.0
+        ref = oracle_conv(x, wt, b * mag, x2=x2, x2_scale=x2s, act1=2, scale=sc, shift=sh * mag, act2=1)
+        kw = dict(x2=None if x2 is None else dev(x2), x2_scale=x2s, act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh * mag), act2=K.ACT_RELU)
+        y = K.conv2d(dev(x), dev(wt), dev(b * mag), **kw)
+        err_x3 = rel_err(host(y), ref)
+        monkeypatch.setattr(K, "EXACT_FP32", True)
+        assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=x2s) != "x3"
+        err_exact = rel_err(host(K.conv2d(dev(x), dev(wt), dev(b * mag), **kw)), ref)
+        monkeypatch.setattr(K, "EXACT_FP32", False)
+        assert tuple(y.shape) == ref.shape and err_x3 <= TOL, (mag, err_x3, err_exact)
+        assert err_x3 <= 4 * err_exact + 2e-7, (mag, err_x3, err_exact)       # the same accuracy class as the exact-fp32 kernels
+    # plain conv, no epilogue; tiny weights (the per-layer scale) and a weight tensor with one huge outlier
+    for wmag, outlier in ((1e-4, False), (1.0, True)):
+        w2 = wt * np.float32(wmag)
+        if outlier:
+            w2 = w2.copy()
+            w2[1, 1, 0, 0] = 37.0
+        x = f32(rng.normal(size=(n, h, w, c1)))
+        x2 = f32(rng.normal(size=(n, h, w, c2))) if c2 else None
+        y0 = K.conv2d(dev(x), dev(w2), x2=None if x2 is None else dev(x2))
+        assert rel_err(host(y0), oracle_conv(x, w2, x2=x2)) <= TOL
+
+
+def test_conv2d_x3_dgrad_and_maxpool_pair(shdr):
+    """the input gradient of a wide 3x3 layer takes the split kernel too (shdr_conv2d_dgrad_f32), and conv + MaxPool2D pairs run as
+    x3 + pooling; both vs the float64 reference"""
+    K = shdr._ops
+    rng = np.random.default_rng(11)
+    n, h, w, cin, cout = 2, 64, 96, 64, 128
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    dz = f32(rng.normal(size=(n, h, w, cout)))
+    dx = K.conv2d_dgrad(dev(dz), dev(wt), (n, h, w, cin), cin, 0, 0)
+    wflip = np.ascontiguousarray(wt[::-1, ::-1].transpose(0, 1, 3, 2))
+    assert rel_err(host(dx), oracle_conv(dz, wflip)) <= TOL
+    y, yp = K.conv2d_maxpool2(dev(x), dev(wt), None, act1=K.ACT_RELU)
+    ref = oracle_conv(x, wt, act1=1)
+    assert rel_err(host(y), ref) <= TOL and np.array_equal(host(yp), ops.max_pool(host(y), 2, 2))
+
+
 def test_conv2d_up2_under_tape_is_two_recorded_ops(shdr):
     """with a gradient tape the fused prologue is not taken: resize and conv are recorded, the gradient reaches x and w"""
     K = shdr._ops
