@@ -22,6 +22,21 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+def same_batchwise(shdr, a, b):
+    """results of the same images computed in different batches / schedules.  With exact-fp32 kernels only (K.EXACT_FP32) they are
+    bit-identical; by default the library may plan a wide 3x3 layer on the split-operand fp16 kernel or on the fused Winograd kernel
+    depending on how many tiles the batch has (both fp32-accurate, rounding differs): then equal to 1e-5 of the tensor scale."""
+    if shdr._ops.EXACT_FP32:
+        return torch.equal(a, b)
+    return float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.fixture(params=[False, True], ids=["default", "exact_fp32"])
+def exact_mode(shdr, request, monkeypatch):
+    monkeypatch.setattr(shdr._ops, "EXACT_FP32", request.param)
+    return request.param
+
+
 def build(shdr, name, seed):
     mod = {"deq": "dequantization_net", "lin": "linearization_net", "hal": "hallucination_net", "ref": "refinement_net"}[name]
     p = nets.init_params(getattr(nets, name + "_spec")(), seed)
@@ -96,16 +111,15 @@ def test_inference_pipeline_matches_golden(shdr):
     np.testing.assert_array_equal(host(hdr), host(out["hdr"]))     # deterministic
 
 
-def test_inference_batch_independence_256(shdr):
+def test_inference_batch_independence_256(shdr, exact_mode):
     """size-independent property at a BASELINE-sized input: images in a batch do not interact
     and the result does not depend on the batch they are computed in (inference BN)."""
     ms = {k: build(shdr, k, 30 + i)[0] for i, k in enumerate(("deq", "lin", "hal", "ref"))}
     run = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
     x = dev(quantised_image(np.random.default_rng(6), (3, 256, 256, 3)))
-    full = host(run(x))
-    single = host(run(x[1:2].contiguous()))
-    np.testing.assert_array_equal(full[1:2], single)
-    assert np.isfinite(full).all() and (full >= 0).all()
+    full = run(x)
+    assert same_batchwise(shdr, run(x[1:2].contiguous()), full[1:2])
+    assert bool(torch.isfinite(full).all()) and float(full.min()) >= 0.0
 
 
 def test_graphed_inference_equals_eager(shdr):
@@ -125,10 +139,10 @@ def test_multi_stream_inference_equals_single_stream(shdr):
     one = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
     two = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"], streams=2)
     x = dev(quantised_image(np.random.default_rng(8), (5, 64, 96, 3)))       # uneven split: 3 + 2
-    np.testing.assert_array_equal(host(two(x)), host(one(x)))
+    assert same_batchwise(shdr, two(x), one(x))
 
 
-def test_full_size_properties_batch16_512(shdr):
+def test_full_size_properties_batch16_512(shdr, exact_mode):
     """BASELINE configs[2] at its FULL size (batch 16 x 512 x 512, deq + lin + hal).  The oracle cannot run this in seconds,
     so the check goes through size-independent properties: the output is finite and non-negative, deterministic (no atomics
     on the inference path), identical under the 2-stream schedule, and images of a batch do not interact -- any slice of
@@ -141,9 +155,9 @@ def test_full_size_properties_batch16_512(shdr):
     assert tuple(full.shape) == (16, 512, 512, 3)
     assert bool(torch.isfinite(full).all()) and float(full.min()) >= 0.0
     assert torch.equal(run(x), full)                                   # deterministic (no atomics on the inference path)
-    assert torch.equal(run2(x), full)                                  # 8 + 8 on two HIP streams
-    assert torch.equal(run(x[5:6].contiguous()), full[5:6])            # one image alone
-    assert torch.equal(run(x[8:12].contiguous()), full[8:12])          # a slice of four
+    assert same_batchwise(shdr, run2(x), full)                         # 8 + 8 on two HIP streams
+    assert same_batchwise(shdr, run(x[5:6].contiguous()), full[5:6])   # one image alone
+    assert same_batchwise(shdr, run(x[8:12].contiguous()), full[8:12])          # a slice of four
 
 
 def test_maximum_tile_size_1024(shdr):
@@ -153,7 +167,7 @@ def test_maximum_tile_size_1024(shdr):
     x = dev(quantised_image(np.random.default_rng(10), (2, 1024, 1024, 3)))
     full = run(x)
     assert tuple(full.shape) == (2, 1024, 1024, 3) and bool(torch.isfinite(full).all()) and float(full.min()) >= 0.0
-    assert torch.equal(run(x[1:2].contiguous()), full[1:2])
+    assert same_batchwise(shdr, run(x[1:2].contiguous()), full[1:2])
     # a tile of the big image is NOT the big image's tile (receptive field), but the two agree away from the tile border:
     # the U-Nets' receptive field is finite only for deq; so compare the Dequantization-Net alone, 96 pixels inside the tile
     with torch.no_grad():

@@ -371,6 +371,7 @@ def test_conv2d_x3_split_fp16_kernel_is_fp32_accurate(shdr, shape, monkeypatch):
     and compared with what the exact-fp32 path (ALGO_AUTO_EXACT: fused Winograd) reaches on the same input.  Ragged tiles, two
     sources with a skip scale, the fused epilogue."""
     n, h, w, c1, c2, cout = shape
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")       # the plan's fill-the-chip threshold is for speed only; read per call
     rng = np.random.default_rng(sum(shape) + 7)
     K = shdr._ops
     wt = f32(rng.normal(size=(3, 3, c1 + c2, cout)) / np.sqrt(9 * (c1 + c2)))
@@ -378,7 +379,7 @@ def test_conv2d_x3_split_fp16_kernel_is_fp32_accurate(shdr, shape, monkeypatch):
     assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=1.0 / 255 if c2 else 1.0) == "x3"
     for mag in (1.0, 1e-3, 1e3):
         x = f32(rng.normal(size=(n, h, w, c1)) * mag)
-        x2 = f32(rng.normal(size=(n, h, w, c2)) * 255.0 * mag) if c2 else None
+        x2 = f32(rng.normal(size=(n, h, w, c2)) * (255.0 * mag if mag <= 1.0 else 8000.0)) if c2 else None    # fp16 range: |x| < 65504
         x2s = 1.0 / 255 if c2 else 1.0
         ref = oracle_conv(x, wt, b * mag, x2=x2, x2_scale=x2s, act1=2, scale=sc, shift=sh * mag, act2=1)
         kw = dict(x2=None if x2 is None else dev(x2), x2_scale=x2s, act1=K.ACT_LRELU, scale=dev(sc), shift=dev(sh * mag), act2=K.ACT_RELU)
@@ -402,9 +403,10 @@ def test_conv2d_x3_split_fp16_kernel_is_fp32_accurate(shdr, shape, monkeypatch):
         assert rel_err(host(y0), oracle_conv(x, w2, x2=x2)) <= TOL
 
 
-def test_conv2d_x3_dgrad_and_maxpool_pair(shdr):
+def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     """the input gradient of a wide 3x3 layer takes the split kernel too (shdr_conv2d_dgrad_f32), and conv + MaxPool2D pairs run as
     x3 + pooling; both vs the float64 reference"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
     K = shdr._ops
     rng = np.random.default_rng(11)
     n, h, w, cin, cout = 2, 64, 96, 64, 128
@@ -414,6 +416,7 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr):
     dx = K.conv2d_dgrad(dev(dz), dev(wt), (n, h, w, cin), cin, 0, 0)
     wflip = np.ascontiguousarray(wt[::-1, ::-1].transpose(0, 1, 3, 2))
     assert rel_err(host(dx), oracle_conv(dz, wflip)) <= TOL
+    assert K.conv2d_plan((n, h, w, cin), wt.shape) == "x3"
     y, yp = K.conv2d_maxpool2(dev(x), dev(wt), None, act1=K.ACT_RELU)
     ref = oracle_conv(x, wt, act1=1)
     assert rel_err(host(y), ref) <= TOL and np.array_equal(host(yp), ops.max_pool(host(y), 2, 2))
