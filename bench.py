@@ -363,14 +363,14 @@ def main():
                 # conv + MaxPool2D(2) pairs of the Hallucination-Net encoder: one launch of the fused Winograd kernel where
                 # it applies (timed here as that launch), otherwise conv2d() [recorded by timed_conv] + maxpool2
                 plan = K.conv2d_plan(tuple(x.shape), tuple(w.shape)) if K.WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 else None
-                if plan != "fused":            # x3 / direct plans: conv2d() [recorded by timed_conv] + maxpool2
+                if plan not in ("fused", "x3"):            # direct plans: conv2d() [recorded by timed_conv] + maxpool2
                     y = timed_conv(x, w, bias, act1=act1)
                     return y, K.maxpool2(y)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = orig_cp(x, w, bias, act1)
                 e1.record()
-                records.append(("winograd_fused_kernel", conv_flops(x, w, 1, None), e0, e1,
+                records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", conv_flops(x, w, 1, None), e0, e1,
                                 "%dx%d %d+0->%d k3 s1 +pool" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3]), False))
                 return out
 
@@ -381,13 +381,14 @@ def main():
                 # the plan is "fused" -- timed here as that launch, with the conv layer's FLOPs --, otherwise resize2x + conv2d()
                 # [the latter recorded by timed_conv]
                 n, h, wd, c = x.shape
-                if not (K.WINOGRAD and K.conv2d_plan((n, 2 * h, 2 * wd, c), tuple(w.shape)) == "fused"):
-                    return timed_conv(K.resize2x(x), w, bias, **kw)      # x3 / direct plans: the up-sampled tensor goes through memory
+                plan = K.conv2d_plan((n, 2 * h, 2 * wd, c), tuple(w.shape)) if K.WINOGRAD else None
+                if plan not in ("fused", "x3"):
+                    return timed_conv(K.resize2x(x), w, bias, **kw)      # direct plans: the up-sampled tensor goes through memory
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = orig_up(x, w, bias, **kw)
                 e1.record()
-                records.append(("winograd_fused_kernel", 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
+                records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
                                 "%dx%d(x2) %d+0->%d k3 s1 +bilinear" % (h, wd, c, w.shape[3]), False))
                 return out
 

@@ -242,7 +242,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
         if ho % 2 or wo % 2:
             raise ValueError("conv2d: pool needs even output height / width")
         yp = torch.empty((n, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
-        if out is None and int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)) != 2:      # only the fused kernel can skip y
+        if out is None and int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)) not in (2, 4):      # the fused Winograd and split kernels can skip y
             out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
     rc = lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
                                           _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _stream())

@@ -157,7 +157,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
 }
 
 // the bilinear 2x prologue runs inside the convolution kernel on the fused Winograd plan (single source, no pooled output)
-inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) { return plan == SHDR_PLAN_WINOGRAD_FUSED && d->C2 == 0; }
+inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) { return (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_X3) && d->C2 == 0; }
 // bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)
 inline size_t up2_bytes(const shdr_conv2d_desc* d, int plan) {
   if (d->prologue != SHDR_PROLOGUE_BILINEAR2X || up2_in_kernel(d, plan)) return 0;
@@ -183,6 +183,7 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
     SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_BILINEAR2X, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown prologue");
     SHDR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->C2 == 0 && x2 == nullptr, SHDR_E_SHAPE,
                  "conv2d_fwd_prepared: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
+    if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_f32(d, x1, nullptr, prepared, bias, scale, shift, y, y_pool, stream);
     if (up2_in_kernel(d, plan)) {
       SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: the bilinear 2x prologue writes y");
       int rcf = shdr_conv2d_winograd_fused_up2_f32(x1, prepared, bias, scale, shift, y, d->N, d->H, d->W, d->C1, d->Cout, d->act1, d->act2, stream);
@@ -202,11 +203,10 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   if (plan == SHDR_PLAN_WINOGRAD_FUSED)
     return shdr_conv2d_winograd_fused2_f32(x1, x2, prepared, bias, scale, shift, y, y_pool, d->N, d->H, d->W, d->C1, d->C2, d->Cout, d->act1,
                                            d->act2, stream);
-  SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd path");
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, stream);
+  SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd and split-operand paths");
   int rc;
-  if (plan == SHDR_PLAN_X3) {
-    rc = shdr_conv2d_fwd_x3_f32(d, x1, x2, prepared, bias, scale, shift, y, stream);
-  } else if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
+  if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
     SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
     const int Cin = d->C1;
     const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);
@@ -270,7 +270,7 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       if (int rc = shdr_conv2d_x3_prepare_filter_f32(wt, u, g.CZ, 0, g.CC, 1.0f, stream)) return rc;
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
-      return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, stream);
+      return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, stream);
     }
     if (g.wino) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);

@@ -18,6 +18,11 @@
 // chunk), split, and written as two fp16 images of 64-byte rows (16-byte slot XOR-swizzled: conflict-free ds_read_b128); the three
 // filter images stream through LDS per tap (12 KB, register-staged one tap ahead, double-buffered).  Per tap and wave: 16 operand
 // reads feed 48 MFMAs.  66 KB of LDS, two blocks per CU.
+// Fused around it: MaxPool2D(2) in the epilogue (the conv + max-pool pairs of hallucination_net.py:43-75 / vgg16.py:72-83: the 2 x 2
+// window is two accumulator rows of a lane and its neighbour lane) and tf.image.resize(x, 2x, BILINEAR) in the prologue (UP = true;
+// hallucination_net.py:86-88, dequantization_net.py:25-27): the block loads the 10 x 10 LOW-RES patch of a chunk (a quarter of the
+// bytes), parks it in 12.5 KB of LDS and builds the 18 x 18 up-sampled patch from it with resize2x_kernel's arithmetic and order
+// (bit-identical to the two-kernel path) on the way into the fp16 images.
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
@@ -38,6 +43,9 @@ constexpr int BN = 64, NT = 4, MT = 4;
 constexpr int IMG_HALVES = BN * 32;                            // one filter image of a tap: [64 couts][32 channels]
 constexpr int UNIT_HALVES = 3 * IMG_HALVES;                    // wh, wh * 2^-11, wl
 constexpr int X3_LDS_BYTES = (2 * PATCH_HALVES + 2 * UNIT_HALVES) * 2;
+constexpr int LRW = 10, LRPIX = LRW * LRW;                     // low-res patch of the up-sampling prologue
+constexpr int LRJ = (LRPIX * 8 + 255) / 256;                   // float4 pieces per thread (4)
+constexpr int X3_LDS_BYTES_UP = X3_LDS_BYTES + LRPIX * 32 * 4;
 
 struct X3Args {
   const float* x1;
@@ -47,8 +55,10 @@ struct X3Args {
   const float* bias;
   const float* scale;
   const float* shift;
-  float* y;
+  float* y;                // [N,H,W,Cout] (or null when only the pooled tensor is wanted)
+  float* yp;               // [N,H/2,W/2,Cout] = MaxPool2D(2)(y), or null
   int N, H, W, C1, C2, Cout, tiles_x, tiles_y, nblk_m, nblk_n, act1, act2;
+  int Hl, Wl;              // UP: x1 is the low-res tensor [N,Hl,Wl,C1], H = 2 Hl, W = 2 Wl
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -57,11 +67,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 __host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }
 
+template <bool UP>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 xsm[];
   _Float16* patch_h = xsm;                                     // [PATCH_HALVES]
   _Float16* patch_l = xsm + PATCH_HALVES;
   _Float16* filt = xsm + 2 * PATCH_HALVES;                     // [2][UNIT_HALVES]
+  float* lrs = reinterpret_cast<float*>(xsm + 2 * PATCH_HALVES + 2 * UNIT_HALVES);      // UP: [LRPIX][32] fp32
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,11 +98,81 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     ppix[j] = ok ? (img * a.H + ih) * a.W + iw : -1;
     pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1) : -1;
+    if (UP) {
+      // bits 0..11: float offset / 4 of the top-left low-res tap in the LDS scratch, 12: right tap one pixel on, 13: bottom tap one row
+      // on, 14: wx = 0.25 (else 0.75), 15: wy = 0.25; -1: zero padding of the up-sampled image
+      if (ok) {
+        const int mr = ih >> 1, mc = iw >> 1;
+        const int ra = (ih & 1) ? mr : max(mr - 1, 0), rb = (ih & 1) ? min(mr + 1, a.Hl - 1) : mr;
+        const int ca = (iw & 1) ? mc : max(mc - 1, 0), cb = (iw & 1) ? min(mc + 1, a.Wl - 1) : mc;
+        const int r0 = (oh0 >> 1) - 1, c0 = (ow0 >> 1) - 1;
+        ppix[j] = (((ra - r0) * LRW + (ca - c0)) * 8 + q) | ((cb != ca) << 12) | ((rb != ra) << 13) | ((iw & 1) << 14) | ((ih & 1) << 15);
+      }
+    }
+  }
+  // UP: low-res pieces of this thread: piece p = tid + 256 j -> (low-res patch pixel, float4)
+  int lpix[LRJ];
+  if (UP) {
+#pragma unroll
+    for (int j = 0; j < LRJ; ++j) {
+      const int p = tid + 256 * j;
+      const int pix = p >> 3;
+      const int ly = pix / LRW, lx = pix - ly * LRW;
+      const int r = (oh0 >> 1) - 1 + ly, c = (ow0 >> 1) - 1 + lx;
+      lpix[j] = (pix < LRPIX && (unsigned)r < (unsigned)a.Hl && (unsigned)c < (unsigned)a.Wl) ? (img * a.Hl + r) * a.Wl + c : -1;
+    }
   }
   const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
   const int nunits = nch * 9;
   f32x4 pr[PJ];
+  auto load_lr = [&](int c) {                                  // UP: low-res chunk c -> the first LRJ registers
+#pragma unroll
+    for (int j = 0; j < LRJ; ++j) {
+      const int q = (tid + 256 * j) & 7;
+      pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (lpix[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(a.x1 + (size_t)(unsigned)lpix[j] * (unsigned)a.C1 + (c << 5) + 4 * q);
+    }
+  };
+  auto park_lr = [&]() {                                       // UP: registers -> LDS scratch [pixel][32]
+#pragma unroll
+    for (int j = 0; j < LRJ; ++j)
+      if (tid + 256 * j < LRPIX * 8) *reinterpret_cast<f32x4*>(lrs + 4 * (tid + 256 * j)) = pr[j];
+  };
+  auto split_store = [&](int dst, const f32x4 v4) {            // one float4 -> 8 bytes in each fp16 image
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = v4[e];
+      h[e] = (_Float16)v;
+      l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
+    }
+    *reinterpret_cast<f16x4*>(patch_h + dst) = h;
+    *reinterpret_cast<f16x4*>(patch_l + dst) = l;
+  };
+  auto expand_store = [&]() {                                  // UP: scratch -> up-sampled 18 x 18 patch (the arithmetic of resize2x_kernel) -> images
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      if (pdst[j] < 0) continue;
+      const int g = ppix[j];
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (g >= 0) {
+        const float* s00 = lrs + 4 * (g & 0xFFF);
+        const int dx = (g >> 12) & 1 ? 32 : 0, dy = (g >> 13) & 1 ? LRW * 32 : 0;
+        const float wx = (g >> 14) & 1 ? 0.25f : 0.75f, wy = (g >> 15) & 1 ? 0.25f : 0.75f;
+        const f32x4 q00 = *reinterpret_cast<const f32x4*>(s00), q01 = *reinterpret_cast<const f32x4*>(s00 + dx);
+        const f32x4 q10 = *reinterpret_cast<const f32x4*>(s00 + dy), q11 = *reinterpret_cast<const f32x4*>(s00 + dy + dx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = q00[e] + (q01[e] - q00[e]) * wx;      // horizontal first, then vertical
+          const float u = q10[e] + (q11[e] - q10[e]) * wx;
+          v[e] = t + (u - t) * wy;
+        }
+      }
+      split_store(pdst[j], v);
+    }
+  };
   auto load_patch = [&](int c) {                               // chunk c -> registers
+    if (UP) { load_lr(c); return; }
     const bool second = c >= nch1;
     const float* src = second ? a.x2 : a.x1;
     const int Cs = second ? a.C2 : a.C1;
@@ -103,19 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     }
   };
   auto store_patch = [&]() {                                   // registers -> the two fp16 images
+    if (UP) { expand_store(); return; }
 #pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-      if (pdst[j] < 0) continue;
-      f16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = pr[j][e];
-        h[e] = (_Float16)v;
-        l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
-      }
-      *reinterpret_cast<f16x4*>(patch_h + pdst[j]) = h;
-      *reinterpret_cast<f16x4*>(patch_l + pdst[j]) = l;
-    }
+    for (int j = 0; j < PJ; ++j)
+      if (pdst[j] >= 0) split_store(pdst[j], pr[j]);
   };
   // ---- filter units: 12 KB per tap = 768 pieces of 16 bytes, three per thread ---------------------------------------------------
   const _Float16* wbase = a.wp + (size_t)pn * nunits * UNIT_HALVES;
@@ -155,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 
   load_patch(0);
   load_filt(0);
+  if (UP) {
+    park_lr();
+    __syncthreads();
+  }
   store_patch();
   store_filt(0);
 #pragma unroll 1
@@ -192,29 +269,50 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       if (u + 1 < nunits) store_filt((u + 1) & 1);             // read after the next barrier
     }
     if (c + 1 < nch) {
-      __syncthreads();                                         // every wave has read the last tap of this chunk's patch
+      if (UP) {
+        park_lr();                                             // the scratch was last read before the tap loop of this chunk
+        __syncthreads();                                       // ... and every wave has read the last tap of this chunk's patch
+      } else {
+        __syncthreads();                                       // every wave has read the last tap of this chunk's patch
+      }
       store_patch();                                           // visible after the barrier at the top of the next tap loop
     }
   }
 
-  // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts) ------------------
+  // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts); the 2 x 2 pooling
+  //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
   const float inv_s = a.hdr[1];
+  const int ow = ow0 + fi;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const int oh = oh0 + wave * MT + mi, ow = ow0 + fi;
-    if (oh >= a.H || ow >= a.W) continue;
-    float* yp = a.y + ((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + n0;
+  for (int mp = 0; mp < MT / 2; ++mp) {
+    const int oh = oh0 + wave * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
+    if (oh >= a.H) continue;                                   // wave-uniform
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int cl = ni * 16 + 4 * fg;
-      f32x4 v = acc[mi][ni] * inv_s;
-      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + cl);
+      f32x4 v[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
-      if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + n0 + cl) + *reinterpret_cast<const f32x4*>(a.shift + n0 + cl);
+      for (int r = 0; r < 2; ++r) {
+        v[r] = acc[2 * mp + r][ni] * inv_s;
+        if (a.bias) v[r] += *reinterpret_cast<const f32x4*>(a.bias + n0 + cl);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
-      *reinterpret_cast<f32x4*>(yp + cl) = v;
+        for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act1);
+        if (a.scale) v[r] = v[r] * *reinterpret_cast<const f32x4*>(a.scale + n0 + cl) + *reinterpret_cast<const f32x4*>(a.shift + n0 + cl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
+        if (a.y && oh + r < a.H && ow < a.W)
+          *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
+      }
+      if (a.yp) {
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m[e] = fmaxf(v[0][e], v[1][e]);
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
+        }
+        if (!(fi & 1) && ow < a.W)
+          *reinterpret_cast<f32x4*>(a.yp + ((size_t)(img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + n0 + cl) = m;
+      }
     }
   }
 }
@@ -291,20 +389,25 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const float* w, float* prepared
 }
 
 extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                      const float* scale, const float* shift, float* y, void* stream) {
-  SHDR_REQUIRE(d && x1 && prepared && y, SHDR_E_NULL, "conv2d_x3: null desc/x1/filter/y");
+                                      const float* scale, const float* shift, float* y, float* y_pool, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or neither y nor y_pool");
+  SHDR_REQUIRE(!y_pool || (d->H % 2 == 0 && d->W % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even H, W");
+  const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X;
+  SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || (up && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
+               "conv2d_x3: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
   SHDR_REQUIRE(shdr_conv2d_x3_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3: layer shape not taken by this kernel");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3: x2 must be given iff C2 > 0");
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3: scale and shift come together");
-  SHDR_REQUIRE(shdr::aligned16(x1) && (!x2 || shdr::aligned16(x2)) && shdr::aligned16(prepared) && shdr::aligned16(y) &&
+  SHDR_REQUIRE(shdr::aligned16(x1) && (!x2 || shdr::aligned16(x2)) && shdr::aligned16(prepared) && (!y || shdr::aligned16(y)) &&
                    (!bias || shdr::aligned16(bias)) && (!scale || (shdr::aligned16(scale) && shdr::aligned16(shift))),
                SHDR_E_ALIGN, "conv2d_x3: tensors must be 16-byte aligned");
   X3Args a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1;
   a.hdr = prepared;
   a.wp = reinterpret_cast<const _Float16*>(prepared + X3_HEADER_FLOATS);
-  a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
+  a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = y_pool;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1; a.C2 = d->C2; a.Cout = d->Cout;
+  a.Hl = d->H / 2; a.Wl = d->W / 2;
   a.tiles_x = (d->W + 15) / 16;
   a.tiles_y = (d->H + 15) / 16;
   a.nblk_m = a.N * a.tiles_x * a.tiles_y;
@@ -313,12 +416,15 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES_UP);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL(conv_x3_kernel, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+  if (up) hipLaunchKernelGGL(conv_x3_kernel<true>, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES_UP, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(conv_x3_kernel<false>, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
   return shdr::check_launch("conv_x3_kernel");
 }

@@ -417,9 +417,32 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     wflip = np.ascontiguousarray(wt[::-1, ::-1].transpose(0, 1, 3, 2))
     assert rel_err(host(dx), oracle_conv(dz, wflip)) <= TOL
     assert K.conv2d_plan((n, h, w, cin), wt.shape) == "x3"
-    y, yp = K.conv2d_maxpool2(dev(x), dev(wt), None, act1=K.ACT_RELU)
+    y, yp = K.conv2d_maxpool2(dev(x), dev(wt), None, act1=K.ACT_RELU)          # ONE launch: the pooling window sits in the epilogue
     ref = oracle_conv(x, wt, act1=1)
     assert rel_err(host(y), ref) <= TOL and np.array_equal(host(yp), ops.max_pool(host(y), 2, 2))
+    assert torch.equal(K.conv2d_maxpool2(dev(x), dev(wt), None, act1=K.ACT_RELU, keep_y=False), yp)      # y never stored
+    assert torch.equal(K.conv2d(dev(x), dev(wt), None, act1=K.ACT_RELU), y)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 128), (1, 13, 19, 32, 64), (1, 8, 8, 256, 64), (1, 1, 3, 32, 64)])
+def test_conv2d_x3_up2_prologue(shdr, shape, monkeypatch):
+    """bilinear 2x fused into the split-operand kernel's patch loader (low-res patch parked in LDS, up-sampled on the way into the
+    fp16 images): vs the float64 oracle and BIT-IDENTICAL to resize2x + the same kernel (the expansion repeats resize2x_kernel's
+    arithmetic); ragged tiles, clamped borders, a 1 x 3 source"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape) + 5)
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, 2 * h, 2 * w, cin), wt.shape) == "x3"
+    up = ops.resize_bilinear_2x(x.astype(np.float64))
+    ref = oracle_conv(up, wt, b, act1=1, scale=sc, shift=sh, act2=1)
+    y = K.conv2d_up2(dev(x), dev(wt), dev(b), act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    two = K.conv2d(K.resize2x(dev(x)), dev(wt), dev(b), act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert torch.equal(y, two)
 
 
 def test_conv2d_up2_under_tape_is_two_recorded_ops(shdr):
