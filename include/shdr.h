@@ -371,14 +371,15 @@ int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const flo
 
 /* fp32 3x3 / stride-1 / SAME convolution on the fp16 matrix pipe (SHDR_PLAN_X3; csrc/conv_x3.hip): x = xh + xl 2^-11, w 2^S = wh + wl in
  * fp16, x w = xh wh + xl (wh 2^-11) + xh wl accumulated in fp32 -- 3 * 2^-22 relative per product, the level of fp32 rounding itself.
+ * Also the 7x7 / stride-2 stem (linearization_net.py:91) as four stride-1 phase launches over the parity-subsampled input, accumulating in y.
  * Needs C1 % 32 == 0, C2 % 32 == 0, Cout % 64 == 0, |x| < 65504.  prepared: shdr_conv2d_x3_filter_elems_f32 floats, written by
  * shdr_conv2d_x3_prepare_filter_f32 (the skip scale of the second source folded in).  y = act2(affine(act1(conv + bias)));
  * y_pool (or NULL) = MaxPool2D(2)(y) from the same epilogue (y may then be NULL); desc.prologue = SHDR_PROLOGUE_BILINEAR2X: x1 is the
  * low-res tensor and the 2x bilinear up-sampling runs inside the kernel's patch loader.
  * Same call sites as shdr_conv2d_winograd_fused2_f32; reached through shdr_conv2d_fwd_prepared_f32 / shdr_conv2d_dgrad_f32. */
 int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d);
-int64_t shdr_conv2d_x3_filter_elems_f32(int Ct, int Cout);
-int shdr_conv2d_x3_prepare_filter_f32(const float* w, float* prepared, int C1, int C2, int Cout, float x2_scale, void* stream);
+int64_t shdr_conv2d_x3_filter_elems_f32(const shdr_conv2d_desc* d);
+int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                            const float* scale, const float* shift, float* y, float* y_pool, void* stream);
 

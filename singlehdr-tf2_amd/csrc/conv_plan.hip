@@ -19,6 +19,7 @@ inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // the Winograd form a 3x3 / stride-1 / SAME layer takes (measured on MI355X, tools/wino_bench.py): the one-kernel fused form beats
 // the direct kernels on every shape it accepts; the three-kernel "planes" form pays from 128 -> 256 / 256 -> 128 channels up
+constexpr int X3_HEADER_FLOATS_PUB = 16;       // header of a packed split-operand filter (conv_x3.hip)
 inline bool is_auto(int algo) { return algo == SHDR_ALGO_AUTO || algo == SHDR_ALGO_AUTO_EXACT; }
 
 int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
@@ -32,9 +33,10 @@ int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   const bool same = d->pad_t == pt && d->pad_l == pl && d->Ho == ho && d->Wo == wo;
   const bool wino_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && same && !has_residual && cout_valid == d->Cout &&
                           d->w_batch_stride == 0 && d->y_pix_stride <= 1 && getenv("SHDR_NO_WINOGRAD") == nullptr;
+  // the split-operand fp16 kernel first (1.4-1.5x the fused Winograd kernel's rate, same accuracy class; also the 7x7 / 2 stem);
+  // SHDR_ALGO_AUTO_EXACT opts out
+  if (d->algo == SHDR_ALGO_AUTO && !has_residual && same && getenv("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
   if (wino_shape) {
-    // the split-operand fp16 kernel first (2-3x the fused Winograd kernel's rate, same accuracy class); SHDR_ALGO_AUTO_EXACT opts out
-    if (d->algo == SHDR_ALGO_AUTO && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
     const bool two_ok = d->C2 == 0 || (d->C2 == d->C1 && d->C1 % 8 == 0 && d->x2_scale == 1.0f);
     if (two_ok && Ct % 8 == 0 && d->Cout % 64 == 0 && Ct >= 32 && (long)d->N * d->H * d->W * Ct < (1L << 32)) return SHDR_PLAN_WINOGRAD_FUSED;
     if (d->C2 == 0 && Ct % 32 == 0 && d->Cout % 16 == 0 && (Ct < d->Cout ? Ct : d->Cout) >= 128 && (long)Ct * d->Cout >= 32768)
@@ -111,7 +113,7 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
   size_t o = 0;
   g.off_wt = o; o += up256(filt);
   g.off_u = o;
-  if (g.x3) o += up256((size_t)shdr_conv2d_x3_filter_elems_f32(g.CZ, g.CC) * sizeof(float));
+  if (g.x3) o += up256((size_t)(X3_HEADER_FLOATS_PUB + ((int64_t)27 * g.CZ * g.CC) / 2) * sizeof(float));
   else if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
   g.off_dz = o; if (g.pad_dz) o += up256((size_t)d->N * d->Ho * d->Wo * g.CZ * sizeof(float));
   g.off_sub = o; if (d->stride == 2 && !(d->KH == 1 && d->KW == 1)) o += up256(filt);
@@ -138,7 +140,7 @@ extern "C" int64_t shdr_conv2d_prepared_filter_elems_f32(const shdr_conv2d_desc*
   if (!d) return -1;
   const int plan = plan_of(d, has_residual != 0);
   const int64_t Ct = d->C1 + d->C2;
-  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_filter_elems_f32((int)Ct, d->Cout);
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_filter_elems_f32(d);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_WINOGRAD_PLANES) return 16 * Ct * d->Cout;
   return (int64_t)d->KH * d->KW * Ct * d->Cout;
 }
@@ -147,7 +149,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
   SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "prepare_filter: null pointer");
   const int plan = plan_of(d, has_residual != 0);
   const int Ct = d->C1 + d->C2;
-  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_prepare_filter_f32(w, prepared, d->C1, d->C2, d->Cout, d->C2 > 0 ? d->x2_scale : 1.0f, stream);
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_prepare_filter_f32(d, w, prepared, stream);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED) return shdr_winograd_filter_packed_f32(w, prepared, Ct, d->Cout, stream);
   if (plan == SHDR_PLAN_WINOGRAD_PLANES) return shdr_winograd_filter_f32(w, prepared, Ct, d->Cout, stream);
   const long total = (long)d->KH * d->KW * Ct * d->Cout;
@@ -157,7 +159,13 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
 }
 
 // the bilinear 2x prologue runs inside the convolution kernel on the fused Winograd plan (single source, no pooled output)
-inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) { return (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_X3) && d->C2 == 0; }
+// ... and on the split-operand plan where the up-sampling pass is dear next to the convolution: the in-kernel expansion costs the
+// block a fixed ~0.2 of a chunk's MFMA time (measured, tools/up2_bench.py), the resize2x pass 1 / Cout of the layer: fused up to 64 couts
+inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) {
+  if (d->C2 != 0) return false;
+  if (plan == SHDR_PLAN_X3) return d->Cout <= 64 || getenv("SHDR_X3_UP_ALWAYS") != nullptr;
+  return plan == SHDR_PLAN_WINOGRAD_FUSED;
+}
 // bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)
 inline size_t up2_bytes(const shdr_conv2d_desc* d, int plan) {
   if (d->prologue != SHDR_PROLOGUE_BILINEAR2X || up2_in_kernel(d, plan)) return 0;
@@ -183,7 +191,7 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
     SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_BILINEAR2X, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown prologue");
     SHDR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->C2 == 0 && x2 == nullptr, SHDR_E_SHAPE,
                  "conv2d_fwd_prepared: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
-    if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_f32(d, x1, nullptr, prepared, bias, scale, shift, y, y_pool, stream);
+    if (plan == SHDR_PLAN_X3 && up2_in_kernel(d, plan)) return shdr_conv2d_fwd_x3_f32(d, x1, nullptr, prepared, bias, scale, shift, y, y_pool, stream);
     if (up2_in_kernel(d, plan)) {
       SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: the bilinear 2x prologue writes y");
       int rcf = shdr_conv2d_winograd_fused_up2_f32(x1, prepared, bias, scale, shift, y, d->N, d->H, d->W, d->C1, d->Cout, d->act1, d->act2, stream);
@@ -268,8 +276,8 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
     c.KH = d->KH; c.KW = d->KW; c.pad_t = (d->KH - 1) - d->pad_t; c.pad_l = (d->KW - 1) - d->pad_l; c.Ho = d->H; c.Wo = d->W;
     if (g.x3) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
-      if (int rc = shdr_conv2d_x3_prepare_filter_f32(wt, u, g.CZ, 0, g.CC, 1.0f, stream)) return rc;
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
+      if (int rc = shdr_conv2d_x3_prepare_filter_f32(&c, wt, u, stream)) return rc;
       return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, stream);
     }
     if (g.wino) {

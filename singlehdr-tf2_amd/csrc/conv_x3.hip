@@ -36,16 +36,21 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int X3_HEADER_FLOATS = 16;                           // [0] max |w| (bits), [1] 2^-S; 64 bytes keep the images 16-byte aligned
-constexpr int PWID = 18, PPIX = PWID * PWID;                   // raw patch of a 16 x 16 tile
-constexpr int PJ = (PPIX * 8 + 255) / 256;                     // float4 pieces per thread and chunk (11)
-constexpr int PATCH_HALVES = PPIX * 32;                        // one fp16 image of the patch
 constexpr int BN = 64, NT = 4, MT = 4;
 constexpr int IMG_HALVES = BN * 32;                            // one filter image of a tap: [64 couts][32 channels]
 constexpr int UNIT_HALVES = 3 * IMG_HALVES;                    // wh, wh * 2^-11, wl
-constexpr int X3_LDS_BYTES = (2 * PATCH_HALVES + 2 * UNIT_HALVES) * 2;
 constexpr int LRW = 10, LRPIX = LRW * LRW;                     // low-res patch of the up-sampling prologue
 constexpr int LRJ = (LRPIX * 8 + 255) / 256;                   // float4 pieces per thread (4)
-constexpr int X3_LDS_BYTES_UP = X3_LDS_BYTES + LRPIX * 32 * 4;
+// KH x KW taps over a 16 x 16 output tile: raw patch (16 + KH - 1) x (16 + KW - 1).  3 x 3 = the stride-1 layers; 4 x 4, 4 x 3, 3 x 4
+// (and 3 x 3) = the four phases of a 7 x 7 / stride-2 layer (see shdr_conv2d_fwd_x3_f32)
+template <int KH, int KW>
+struct X3G {
+  static constexpr int PH = 16 + KH - 1, PWID = 16 + KW - 1, PPIX = PH * PWID;
+  static constexpr int PJ = (PPIX * 8 + 255) / 256;           // float4 pieces per thread and chunk
+  static constexpr int PATCH_HALVES = PPIX * 32;              // one fp16 image of the patch
+  static constexpr int LDS_BYTES = (2 * PATCH_HALVES + 2 * UNIT_HALVES) * 2;
+  static constexpr int LDS_BYTES_UP = LDS_BYTES + LRPIX * 32 * 4;
+};
 
 struct X3Args {
   const float* x1;
@@ -57,8 +62,12 @@ struct X3Args {
   const float* shift;
   float* y;                // [N,H,W,Cout] (or null when only the pooled tensor is wanted)
   float* yp;               // [N,H/2,W/2,Cout] = MaxPool2D(2)(y), or null
+  const float* yin;        // partial sums of earlier phases to add (same layout as y), or null
   int N, H, W, C1, C2, Cout, tiles_x, tiles_y, nblk_m, nblk_n, act1, act2;
   int Hl, Wl;              // UP: x1 is the low-res tensor [N,Hl,Wl,C1], H = 2 Hl, W = 2 Wl
+  int Hin, Win;            // input tensor [N,Hin,Win,C]; tap (kh, kw) of output (oh, ow) reads input (in_s (oh + kh) + bh, in_s (ow + kw) + bw)
+  int in_s, bh, bw;        // stride-1 3x3 SAME: in_s = 1, bh = bw = -1
+  int final;               // 0: store the raw partial sum (another phase follows), 1: the epilogue
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -67,8 +76,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 __host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }
 
-template <bool UP>
+template <bool UP, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
+  using G = X3G<KH, KW>;
+  constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, PATCH_HALVES = G::PATCH_HALVES, NTAPS = KH * KW;
+  static_assert(!UP || (KH == 3 && KW == 3), "the up-sampling prologue belongs to the 3 x 3 stride-1 form");
   extern __shared__ __attribute__((aligned(16))) _Float16 xsm[];
   _Float16* patch_h = xsm;                                     // [PATCH_HALVES]
   _Float16* patch_l = xsm + PATCH_HALVES;
@@ -94,9 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     const int p = tid + 256 * j;
     const int pix = p >> 3, q = p & 7;
     const int py = pix / PWID, px = pix - py * PWID;
-    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
-    const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-    ppix[j] = ok ? (img * a.H + ih) * a.W + iw : -1;
+    const int ih = a.in_s * (oh0 + py) + a.bh, iw = a.in_s * (ow0 + px) + a.bw;
+    const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+    ppix[j] = ok ? (img * a.Hin + ih) * a.Win + iw : -1;
     pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1) : -1;
     if (UP) {
       // bits 0..11: float offset / 4 of the top-left low-res tap in the LDS scratch, 12: right tap one pixel on, 13: bottom tap one row
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     }
   }
   const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
-  const int nunits = nch * 9;
+  const int nunits = nch * NTAPS;
   f32x4 pr[PJ];
   auto load_lr = [&](int c) {                                  // UP: low-res chunk c -> the first LRJ registers
 #pragma unroll
@@ -236,13 +248,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   store_filt(0);
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) load_patch(c + 1);                        // lands under the nine taps of this chunk
+    if (c + 1 < nch) load_patch(c + 1);                        // lands under the taps of this chunk
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int u = c * 9 + tap;
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int u = c * NTAPS + tap;
       __syncthreads();                                         // unit u (and, at tap 0, the patch) is in LDS; buffer (u + 1) & 1 is free
       if (u + 1 < nunits) load_filt(u + 1);
-      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int kh = tap / KW, kw = tap - KW * kh;
       const _Float16* F = filt + (u & 1) * UNIT_HALVES;
       f16x8 wh[NT], ws[NT], wl[NT], ph[MT], pl[MT];
 #pragma unroll
@@ -294,6 +306,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         v[r] = acc[2 * mp + r][ni] * inv_s;
+        const bool inside = oh + r < a.H && ow < a.W;
+        if (a.yin && inside) v[r] += *reinterpret_cast<const f32x4*>(a.yin + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl);
+        if (!a.final) {
+          if (inside) *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
+          continue;
+        }
         if (a.bias) v[r] += *reinterpret_cast<const f32x4*>(a.bias + n0 + cl);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act1);
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         if (a.y && oh + r < a.H && ow < a.W)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
       }
-      if (a.yp) {
+      if (a.yp && a.final) {
         f32x4 m;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -326,8 +344,9 @@ __global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict_
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bit patterns
 }
 // packed[nb][u = chunk * 9 + tap][image][co][k]: w * x2-scale * 2^S split into wh, wh * 2^-11, wl
+// taps of the packed filter = the sub-filter w[p0 + step * a][q0 + step * b], a < TH, b < TW, of a KWF-wide filter
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int Ct,
-                                                      int C1, int Cout, float x2_scale) {
+                                                      int C1, int Cout, float x2_scale, int KWF, int TH, int TW, int p0, int q0, int step) {
   const float mx = fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[0]) * fmaxf(1.0f, fabsf(x2_scale)), 1e-30f);
   int ex;
   frexpf(mx, &ex);                                             // mx = f * 2^ex, f in [0.5, 1)
@@ -335,13 +354,16 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
   S = S < -100 ? -100 : (S > 100 ? 100 : S);
   const float s = ldexpf(1.0f, S);
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
-  const int nunits = (Ct >> 5) * 9;
+  const int ntaps = TH * TW;
+  const int nunits = (Ct >> 5) * ntaps;
   const long total = (long)(Cout / 64) * nunits * 64 * 32;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int k = (int)(e & 31), co = (int)((e >> 5) & 63);
     const long t = e >> 11;
     const int u = (int)(t % nunits), nb = (int)(t / nunits);
-    const int chunk = u / 9, tap = u - 9 * chunk;
+    const int chunk = u / ntaps, t2 = u - ntaps * chunk;
+    const int ta = t2 / TW, tb = t2 - TW * ta;
+    const int tap = (p0 + step * ta) * KWF + (q0 + step * tb);
     const int ch = chunk * 32 + k;
     float v = w[((size_t)tap * Ct + ch) * Cout + nb * 64 + co] * s;
     if (ch >= C1) v *= x2_scale;
@@ -355,46 +377,105 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
 
 }  // namespace
 
+namespace {
+
+struct X3Phase { int th, tw, p0, q0, step, bh, bw; };
+// 3 x 3 / stride 1: one "phase" (all nine taps).  7 x 7 / stride 2 (linearization_net.py:91): input pixels of one row / column parity
+// meet the filter taps of one parity only, so the layer is the sum of four stride-1 correlations of the parity-subsampled input with
+// the 4 x 4, 4 x 3, 3 x 4 and 3 x 3 sub-filters -- exactly the 49 taps, each phase one launch accumulating into y.
+int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
+  if (d->stride == 1) {
+    ph[0] = X3Phase{3, 3, 0, 0, 1, -d->pad_t, -d->pad_l};
+    return 1;
+  }
+  int n = 0;
+  for (int p0 = 0; p0 < 2; ++p0)
+    for (int q0 = 0; q0 < 2; ++q0) ph[n++] = X3Phase{(d->KH - p0 + 1) / 2, (d->KW - q0 + 1) / 2, p0, q0, 2, p0 - d->pad_t, q0 - d->pad_l};
+  return n;
+}
+inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + ((int64_t)3 * p.th * p.tw * Ct * Cout) / 2; }
+
+template <bool UP, int KH, int KW>
+int launch_x3(const X3Args& a, hipStream_t st) {
+  constexpr int lds = UP ? X3G<KH, KW>::LDS_BYTES_UP : X3G<KH, KW>::LDS_BYTES;
+  static bool attr_done[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (!attr_done[dev_slot]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done[dev_slot] = true;
+  }
+  const long nblk = (long)a.nblk_m * a.nblk_n;
+  if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
+  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  return shdr::check_launch("conv_x3_kernel");
+}
+
+}  // namespace
+
 extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
-  if (!d || d->stride != 1 || d->KH != 3 || d->KW != 3 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
-  if (d->C1 % 32 || d->C2 % 32 || d->Cout % 64 || d->C1 <= 0) return 0;
+  if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout % 64) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv != d->Cout || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
   if (getenv("SHDR_NO_X3")) return 0;
+  if (d->stride == 1) {
+    if (d->KH != 3 || d->KW != 3 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
+  } else {
+    // the 7 x 7 / stride-2 stem with TF SAME padding (one source, no prologue)
+    int ho = 0, wo = 0, pt = 0, pl = 0;
+    shdr_same_pad(d->H, 7, 2, &ho, &pt);
+    shdr_same_pad(d->W, 7, 2, &wo, &pl);
+    if (d->stride != 2 || d->KH != 7 || d->KW != 7 || d->C2 != 0 || d->prologue != SHDR_PROLOGUE_NONE || d->Ho != ho || d->Wo != wo || d->pad_t != pt ||
+        d->pad_l != pl || getenv("SHDR_NO_X3_STRIDE2"))
+      return 0;
+  }
   // enough blocks to fill the chip: the deepest, smallest maps stay on the fused Winograd kernel (8 x 16 tiles)
-  const long blocks = (long)d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16) * (d->Cout / 64);
+  const long blocks = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 64);
   long min_blocks = 384;
   if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
   return blocks >= min_blocks ? 1 : 0;
 }
 
-extern "C" int64_t shdr_conv2d_x3_filter_elems_f32(int Ct, int Cout) {
-  if (Ct <= 0 || Cout <= 0 || Ct % 32 || Cout % 64) return -1;
-  return X3_HEADER_FLOATS + ((int64_t)3 * 9 * Ct * Cout) / 2;      // header + three fp16 images, in floats
+extern "C" int64_t shdr_conv2d_x3_filter_elems_f32(const shdr_conv2d_desc* d) {
+  if (!d || d->C1 <= 0 || (d->C1 + d->C2) % 32 || d->Cout % 64 || (d->stride != 1 && d->stride != 2)) return -1;
+  X3Phase ph[4];
+  const int n = x3_phases(d, ph);
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) total += x3_phase_floats(ph[i], d->C1 + d->C2, d->Cout);
+  return total;
 }
 
-extern "C" int shdr_conv2d_x3_prepare_filter_f32(const float* w, float* prepared, int C1, int C2, int Cout, float x2_scale, void* stream) {
-  SHDR_REQUIRE(w && prepared, SHDR_E_NULL, "conv2d_x3_prepare_filter: null pointer");
-  const int Ct = C1 + C2;
-  SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && C1 % 32 == 0 && Cout > 0 && Cout % 64 == 0, SHDR_E_SHAPE, "conv2d_x3_prepare_filter: need C %% 32 == 0, Cout %% 64 == 0");
+extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream) {
+  SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "conv2d_x3_prepare_filter: null pointer");
+  const int Ct = d->C1 + d->C2;
+  SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && d->C1 % 32 == 0 && d->Cout > 0 && d->Cout % 64 == 0, SHDR_E_SHAPE,
+               "conv2d_x3_prepare_filter: need C %% 32 == 0, Cout %% 64 == 0");
   SHDR_REQUIRE(shdr::aligned16(prepared), SHDR_E_ALIGN, "conv2d_x3_prepare_filter: prepared must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(prepared, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
-  const long n = 9L * Ct * Cout;
-  hipLaunchKernelGGL(x3_absmax_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, st, w, n, reinterpret_cast<unsigned*>(prepared));
-  hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, st, w, prepared,
-                     reinterpret_cast<_Float16*>(prepared + X3_HEADER_FLOATS), Ct, C1, Cout, x2_scale);
+  const float x2s = d->C2 > 0 ? d->x2_scale : 1.0f;
+  X3Phase ph[4];
+  const int n = x3_phases(d, ph);
+  const long nw = (long)d->KH * d->KW * Ct * d->Cout;
+  float* out = prepared;
+  for (int i = 0; i < n; ++i) {
+    if (hipMemsetAsync(out, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(shdr::stream_grid(nw)), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
+    const long np = (long)ph[i].th * ph[i].tw * Ct * d->Cout;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
+                       d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);
+    out += x3_phase_floats(ph[i], Ct, d->Cout);
+  }
   return shdr::check_launch("conv2d_x3_prepare_filter");
 }
 
 extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                       const float* scale, const float* shift, float* y, float* y_pool, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or neither y nor y_pool");
-  SHDR_REQUIRE(!y_pool || (d->H % 2 == 0 && d->W % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even H, W");
+  SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even Ho, Wo");
   const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X;
-  SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || (up && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
-               "conv2d_x3: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
+  SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || (up && d->stride == 1 && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
+               "conv2d_x3: the bilinear 2x prologue takes a stride-1 layer, one source and even (up-sampled) H, W");
   SHDR_REQUIRE(shdr_conv2d_x3_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3: layer shape not taken by this kernel");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3: x2 must be given iff C2 > 0");
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3: scale and shift come together");
@@ -403,28 +484,35 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
                SHDR_E_ALIGN, "conv2d_x3: tensors must be 16-byte aligned");
   X3Args a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1;
-  a.hdr = prepared;
-  a.wp = reinterpret_cast<const _Float16*>(prepared + X3_HEADER_FLOATS);
   a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = y_pool;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1; a.C2 = d->C2; a.Cout = d->Cout;
+  a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C1 = d->C1; a.C2 = d->C2; a.Cout = d->Cout;
+  a.Hin = d->H; a.Win = d->W;
   a.Hl = d->H / 2; a.Wl = d->W / 2;
-  a.tiles_x = (d->W + 15) / 16;
-  a.tiles_y = (d->H + 15) / 16;
+  a.tiles_x = (a.W + 15) / 16;
+  a.tiles_y = (a.H + 15) / 16;
   a.nblk_m = a.N * a.tiles_x * a.tiles_y;
   a.nblk_n = a.Cout / 64;
   a.act1 = d->act1; a.act2 = d->act2;
-  static bool attr_done[shdr::kMaxDevices] = {};
-  const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES_UP);
-    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done[dev_slot] = true;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  X3Phase ph[4];
+  const int n = x3_phases(d, ph);
+  SHDR_REQUIRE(n == 1 || y, SHDR_E_NULL, "conv2d_x3: the phases of a stride-2 layer accumulate in y");
+  const int Ct = d->C1 + d->C2;
+  const float* pk = prepared;
+  for (int i = 0; i < n; ++i) {
+    a.hdr = pk;
+    a.wp = reinterpret_cast<const _Float16*>(pk + X3_HEADER_FLOATS);
+    a.in_s = ph[i].step; a.bh = ph[i].bh; a.bw = ph[i].bw;
+    a.yin = i > 0 ? y : nullptr;
+    a.final = i == n - 1;
+    int rc;
+    if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
+    else if (ph[i].th == 4 && ph[i].tw == 4) rc = launch_x3<false, 4, 4>(a, st);
+    else if (ph[i].th == 4 && ph[i].tw == 3) rc = launch_x3<false, 4, 3>(a, st);
+    else if (ph[i].th == 3 && ph[i].tw == 4) rc = launch_x3<false, 3, 4>(a, st);
+    else rc = shdr::fail(SHDR_E_SHAPE, "conv2d_x3: no kernel for a %d x %d phase", ph[i].th, ph[i].tw);
+    if (rc) return rc;
+    pk += x3_phase_floats(ph[i], Ct, d->Cout);
   }
-  const long nblk = (long)a.nblk_m * a.nblk_n;
-  if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
-  if (up) hipLaunchKernelGGL(conv_x3_kernel<true>, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES_UP, reinterpret_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL(conv_x3_kernel<false>, dim3((unsigned)nblk), dim3(256), X3_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
-  return shdr::check_launch("conv_x3_kernel");
+  return SHDR_OK;
 }

@@ -424,12 +424,35 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     assert torch.equal(K.conv2d(dev(x), dev(wt), None, act1=K.ACT_RELU), y)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96, 96, 64), (1, 61, 75, 96, 64), (1, 32, 34, 32, 128), (1, 17, 16, 64, 64)])
+def test_conv2d_x3_stride2_stem_as_four_phases(shdr, shape, monkeypatch):
+    """the 7x7 / stride-2 stem of the Linearization-Net (linearization_net.py:91) on the split-operand kernel: four stride-1 phase
+    launches (4x4, 4x3, 3x4, 3x3 sub-filters over the parity-subsampled input) accumulating in y, folded-BN epilogue in the last;
+    even and odd sizes (TF SAME: pad 2 / 3 resp. 3 / 3), vs the float64 oracle at the exact-fp32 kernels' bar"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape) + 3)
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(7, 7, cin, cout)) / np.sqrt(49 * cin))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, h, w, cin), wt.shape, stride=2) == "x3"
+    ref = oracle_conv(x, wt, b, stride=2, scale=sc, shift=sh, act2=1)
+    y = K.conv2d(dev(x), dev(wt), dev(b), stride=2, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    monkeypatch.setattr(K, "EXACT_FP32", True)
+    assert K.conv2d_plan((n, h, w, cin), wt.shape, stride=2) == "mfma"
+    err_exact = rel_err(host(K.conv2d(dev(x), dev(wt), dev(b), stride=2, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)), ref)
+    assert rel_err(host(y), ref) <= 4 * err_exact + 2e-7
+
+
 @pytest.mark.parametrize("shape", [(2, 24, 40, 64, 128), (1, 13, 19, 32, 64), (1, 8, 8, 256, 64), (1, 1, 3, 32, 64)])
 def test_conv2d_x3_up2_prologue(shdr, shape, monkeypatch):
     """bilinear 2x fused into the split-operand kernel's patch loader (low-res patch parked in LDS, up-sampled on the way into the
     fp16 images): vs the float64 oracle and BIT-IDENTICAL to resize2x + the same kernel (the expansion repeats resize2x_kernel's
     arithmetic); ragged tiles, clamped borders, a 1 x 3 source"""
     monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    monkeypatch.setenv("SHDR_X3_UP_ALWAYS", "1")        # the plan fuses the prologue up to 64 couts only (speed); here every case
     n, h, w, cin, cout = shape
     rng = np.random.default_rng(sum(shape) + 5)
     K = shdr._ops
