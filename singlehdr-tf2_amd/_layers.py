@@ -118,7 +118,9 @@ class Conv2D(Layer):
         if self._padded is None or self._padded[0] != key:
             pad = torch.zeros((k.shape[0], k.shape[1], cin_pad, cout_pad), device=k.device, dtype=k.dtype)
             pad[:, :, :k.shape[2], :k.shape[3]] = k
-            self._padded = (key, pad.contiguous())
+            pad = pad.contiguous()
+            pad._shdr_const = True         # one tensor per parameter version: the library's prepared form is cached on it (_ops._prepared_filter)
+            self._padded = (key, pad)
         return self._padded[1]
 
     def kernel_x2_scaled(self, c1, scale):

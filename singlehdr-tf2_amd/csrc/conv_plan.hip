@@ -159,11 +159,12 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
 }
 
 // the bilinear 2x prologue runs inside the convolution kernel on the fused Winograd plan (single source, no pooled output)
-// ... and on the split-operand plan where the up-sampling pass is dear next to the convolution: the in-kernel expansion costs the
-// block a fixed ~0.2 of a chunk's MFMA time (measured, tools/up2_bench.py), the resize2x pass 1 / Cout of the layer: fused up to 64 couts
+// ... and on the split-operand plan where the up-sampling pass is dear next to the convolution: the in-kernel expansion is repeated by
+// every 64-cout block of a tile, the resize2x pass costs 1 / Cout of the layer -- measured (tools/up2_bench.py, 16 x 512^2 step shapes):
+// 128 -> 64 2.70 -> 2.03 ms, 256 -> 128 2.13 -> 1.88, 512 -> 256 1.86 -> 1.79, 512 -> 512 0.91 -> 0.96: fused up to 256 couts
 inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) {
   if (d->C2 != 0) return false;
-  if (plan == SHDR_PLAN_X3) return d->Cout <= 64 || getenv("SHDR_X3_UP_ALWAYS") != nullptr;
+  if (plan == SHDR_PLAN_X3) return d->Cout <= 256 || getenv("SHDR_X3_UP_ALWAYS") != nullptr;
   return plan == SHDR_PLAN_WINOGRAD_FUSED;
 }
 // bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)

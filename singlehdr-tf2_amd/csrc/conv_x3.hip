@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, PATCH_HALVES = G::PATCH_HALVES, NTAPS = KH * KW;
   static_assert(!UP || (KH == 3 && KW == 3), "the up-sampling prologue belongs to the 3 x 3 stride-1 form");
   extern __shared__ __attribute__((aligned(16))) _Float16 xsm[];
-  _Float16* patch_h = xsm;                                     // [PATCH_HALVES]
-  _Float16* patch_l = xsm + PATCH_HALVES;
-  _Float16* filt = xsm + 2 * PATCH_HALVES;                     // [2][UNIT_HALVES]
-  float* lrs = reinterpret_cast<float*>(xsm + 2 * PATCH_HALVES + 2 * UNIT_HALVES);      // UP: [LRPIX][32] fp32
+  // LDS regions as expressions of the __shared__ symbol (pointer VARIABLES captured by the lambdas below lost their address space: the
+  // compiler kept them as 64-bit generic pointers in scratch and reloaded them inside the tap loop)
+#define patch_h (xsm)                                          /* [PATCH_HALVES] */
+#define patch_l (xsm + PATCH_HALVES)
+#define filt (xsm + 2 * PATCH_HALVES)                          /* [2][UNIT_HALVES] */
+#define lrs (reinterpret_cast<float*>(xsm + 2 * PATCH_HALVES + 2 * UNIT_HALVES))       /* UP: [LRPIX][32] fp32 */
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   int ppix[PJ];                                                // pixel index in the image tensor, -1: padding / beyond the patch
   int pdst[PJ];                                                // half offset of the 8-byte destination inside an image
 #pragma unroll
-  for (int j = 0; j < PJ; ++j) {
+  for (int j = 0; j < (UP ? 0 : PJ); ++j) {
     const int p = tid + 256 * j;
     const int pix = p >> 3, q = p & 7;
     const int py = pix / PWID, px = pix - py * PWID;
@@ -110,17 +112,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
     ppix[j] = ok ? (img * a.Hin + ih) * a.Win + iw : -1;
     pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1) : -1;
-    if (UP) {
-      // bits 0..11: float offset / 4 of the top-left low-res tap in the LDS scratch, 12: right tap one pixel on, 13: bottom tap one row
-      // on, 14: wx = 0.25 (else 0.75), 15: wy = 0.25; -1: zero padding of the up-sampled image
-      if (ok) {
-        const int mr = ih >> 1, mc = iw >> 1;
-        const int ra = (ih & 1) ? mr : max(mr - 1, 0), rb = (ih & 1) ? min(mr + 1, a.Hl - 1) : mr;
-        const int ca = (iw & 1) ? mc : max(mc - 1, 0), cb = (iw & 1) ? min(mc + 1, a.Wl - 1) : mc;
-        const int r0 = (oh0 >> 1) - 1, c0 = (ow0 >> 1) - 1;
-        ppix[j] = (((ra - r0) * LRW + (ca - c0)) * 8 + q) | ((cb != ca) << 12) | ((rb != ra) << 13) | ((iw & 1) << 14) | ((ih & 1) << 15);
-      }
-    }
   }
   // UP: low-res pieces of this thread: piece p = tid + 256 j -> (low-res patch pixel, float4)
   int lpix[LRJ];
@@ -137,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
   const int nunits = nch * NTAPS;
   f32x4 pr[PJ];
-  auto load_lr = [&](int c) {                                  // UP: low-res chunk c -> the first LRJ registers
+  auto load_lr = [&](int c) __attribute__((always_inline)) {                                  // UP: low-res chunk c -> the first LRJ registers
 #pragma unroll
     for (int j = 0; j < LRJ; ++j) {
       const int q = (tid + 256 * j) & 7;
@@ -145,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       if (lpix[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(a.x1 + (size_t)(unsigned)lpix[j] * (unsigned)a.C1 + (c << 5) + 4 * q);
     }
   };
-  auto park_lr = [&]() {                                       // UP: registers -> LDS scratch [pixel][32]
+  auto park_lr = [&]() __attribute__((always_inline)) {                                       // UP: registers -> LDS scratch [pixel][32]
 #pragma unroll
     for (int j = 0; j < LRJ; ++j)
       if (tid + 256 * j < LRPIX * 8) *reinterpret_cast<f32x4*>(lrs + 4 * (tid + 256 * j)) = pr[j];
   };
-  auto split_store = [&](int dst, const f32x4 v4) {            // one float4 -> 8 bytes in each fp16 image
+  auto split_store = [&](int dst, const f32x4 v4) __attribute__((always_inline)) {            // one float4 -> 8 bytes in each fp16 image
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -161,16 +152,27 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     *reinterpret_cast<f16x4*>(patch_h + dst) = h;
     *reinterpret_cast<f16x4*>(patch_l + dst) = l;
   };
-  auto expand_store = [&]() {                                  // UP: scratch -> up-sampled 18 x 18 patch (the arithmetic of resize2x_kernel) -> images
+  auto expand_store = [&]() __attribute__((always_inline)) {   // UP: scratch -> up-sampled 18 x 18 patch (the arithmetic of resize2x_kernel) -> images
+    // the geometry of a piece is recomputed per chunk (a few integer operations) instead of being held in 22 registers: the
+    // expansion needs them for its four taps
+    const int r0 = (oh0 >> 1) - 1, c0 = (ow0 >> 1) - 1;
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));                               // computed HERE: hoisted out of the chunk loop the 11 geometries are 90 live registers (spills)
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
-      if (pdst[j] < 0) continue;
-      const int g = ppix[j];
+      const int p = t0 + 256 * j;
+      const int pix = p >> 3, q = p & 7;
+      if (pix >= PPIX) continue;
+      const int py = pix / PWID, px = pix - py * PWID;
+      const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (g >= 0) {
-        const float* s00 = lrs + 4 * (g & 0xFFF);
-        const int dx = (g >> 12) & 1 ? 32 : 0, dy = (g >> 13) & 1 ? LRW * 32 : 0;
-        const float wx = (g >> 14) & 1 ? 0.25f : 0.75f, wy = (g >> 15) & 1 ? 0.25f : 0.75f;
+      if ((unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        const int mr = ih >> 1, mc = iw >> 1;
+        const int ra = (ih & 1) ? mr : max(mr - 1, 0), rb = (ih & 1) ? min(mr + 1, a.Hl - 1) : mr;
+        const int ca = (iw & 1) ? mc : max(mc - 1, 0), cb = (iw & 1) ? min(mc + 1, a.Wl - 1) : mc;
+        const float* s00 = lrs + ((ra - r0) * LRW + (ca - c0)) * 32 + 4 * q;
+        const int dx = (cb - ca) * 32, dy = (rb - ra) * LRW * 32;
+        const float wx = (iw & 1) ? 0.25f : 0.75f, wy = (ih & 1) ? 0.25f : 0.75f;
         const f32x4 q00 = *reinterpret_cast<const f32x4*>(s00), q01 = *reinterpret_cast<const f32x4*>(s00 + dx);
         const f32x4 q10 = *reinterpret_cast<const f32x4*>(s00 + dy), q11 = *reinterpret_cast<const f32x4*>(s00 + dy + dx);
 #pragma unroll
@@ -180,10 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
           v[e] = t + (u - t) * wy;
         }
       }
-      split_store(pdst[j], v);
+      split_store(pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1), v);
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);            // two pieces (32 registers of taps) in flight, not eleven: no spills
     }
   };
-  auto load_patch = [&](int c) {                               // chunk c -> registers
+  auto load_patch = [&](int c) __attribute__((always_inline)) {                               // chunk c -> registers
     if (UP) { load_lr(c); return; }
     const bool second = c >= nch1;
     const float* src = second ? a.x2 : a.x1;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       if (ppix[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)ppix[j] * (unsigned)Cs + c0 + 4 * q);
     }
   };
-  auto store_patch = [&]() {                                   // registers -> the two fp16 images
+  auto store_patch = [&]() __attribute__((always_inline)) {                                   // registers -> the two fp16 images
     if (UP) { expand_store(); return; }
 #pragma unroll
     for (int j = 0; j < PJ; ++j)
@@ -212,12 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     fdst[j] = im * IMG_HALVES + co * 32 + 8 * (slot ^ f4(co));
   }
   u32x4 fr[3];
-  auto load_filt = [&](int u) {
+  auto load_filt = [&](int u) __attribute__((always_inline)) {
     const u32x4* g = reinterpret_cast<const u32x4*>(wbase + (size_t)u * UNIT_HALVES);
 #pragma unroll
     for (int j = 0; j < 3; ++j) fr[j] = g[tid + 256 * j];
   };
-  auto store_filt = [&](int buf) {
+  auto store_filt = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(filt + buf * UNIT_HALVES + fdst[j]) = fr[j];
   };
@@ -334,6 +337,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     }
   }
 }
+
+#undef patch_h
+#undef patch_l
+#undef filt
+#undef lrs
 
 // ---- filter preparation ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {

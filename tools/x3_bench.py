@@ -16,6 +16,7 @@ SHAPES = [  # n, h, w, c1, c2, cout
     (16, 128, 128, 256, 0, 256), (16, 64, 64, 256, 0, 512), (16, 64, 64, 512, 0, 512), (16, 32, 32, 512, 0, 512),
     (16, 512, 512, 128, 0, 64), (16, 256, 256, 256, 0, 128), (16, 128, 128, 512, 0, 256), (16, 128, 128, 64, 64, 64),
     (16, 128, 128, 32, 0, 64), (16, 64, 64, 128, 128, 128),
+    (16, 512, 512, 96, 0, 64, 7, 2),          # the Linearization-Net stem: four phase launches
 ]
 
 
@@ -33,18 +34,20 @@ def timeit(fn, reps=10):
 
 
 with torch.no_grad():
-    for n, h, w, c1, c2, cout in SHAPES:
+    for shape in SHAPES:
+        n, h, w, c1, c2, cout = shape[:6]
+        k, st = (shape[6], shape[7]) if len(shape) > 6 else (3, 1)
         x = torch.randn(n, h, w, c1, device="cuda")
         x2 = torch.randn(n, h, w, c2, device="cuda") if c2 else None
-        wt = (torch.randn(3, 3, c1 + c2, cout, device="cuda") / (3 * (c1 + c2) ** 0.5)).requires_grad_(True)   # persistent: prepared once
+        wt = (torch.randn(k, k, c1 + c2, cout, device="cuda") / (k * (c1 + c2) ** 0.5)).requires_grad_(True)   # persistent: prepared once
         b = torch.randn(cout, device="cuda")
-        flops = 2.0 * n * h * w * (c1 + c2) * cout * 9
+        flops = 2.0 * n * (h // st) * (w // st) * (c1 + c2) * cout * k * k
         res = {}
         for exact in (False, True):
             K.EXACT_FP32 = exact
-            plan = K.conv2d_plan((n, h, w, c1), tuple(wt.shape), c2=c2)
-            t = timeit(lambda: K.conv2d(x, wt, b, x2=x2, act1=K.ACT_RELU))
-            res[exact] = (plan, t, K.conv2d(x, wt, b, x2=x2, act1=K.ACT_RELU))
+            plan = K.conv2d_plan((n, h, w, c1), tuple(wt.shape), c2=c2, stride=st)
+            t = timeit(lambda: K.conv2d(x, wt, b, stride=st, x2=x2, act1=K.ACT_RELU))
+            res[exact] = (plan, t, K.conv2d(x, wt, b, stride=st, x2=x2, act1=K.ACT_RELU))
         K.EXACT_FP32 = False
         d = float((res[False][2] - res[True][2]).abs().max() / res[True][2].abs().max())
         print("%3dx%-3d %3d+%-3d->%-3d  %-6s %6.3f ms %6.1f TF/s alg   | exact %-6s %6.3f ms %6.1f TF/s alg   x%.2f   max|diff|/max %.1e"
