@@ -113,7 +113,7 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
   size_t o = 0;
   g.off_wt = o; o += up256(filt);
   g.off_u = o;
-  if (g.x3) o += up256((size_t)(X3_HEADER_FLOATS_PUB + ((int64_t)27 * g.CZ * g.CC) / 2) * sizeof(float));
+  if (g.x3) o += up256((size_t)(X3_HEADER_FLOATS_PUB + (int64_t)9 * g.CZ * g.CC) * sizeof(float));
   else if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
   g.off_dz = o; if (g.pad_dz) o += up256((size_t)d->N * d->Ho * d->Wo * g.CZ * sizeof(float));
   g.off_sub = o; if (d->stride == 2 && !(d->KH == 1 && d->KW == 1)) o += up256(filt);

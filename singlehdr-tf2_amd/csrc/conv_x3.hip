@@ -7,7 +7,8 @@
 // (it is stored scaled).  w' = w * 2^S (S per layer: max |w'| in [2^13, 2^14), so the low term of a weight is a normal fp16 number
 // down to |w| = max |w| * 2^-17) = wh + wl.  Then
 //     x * w' = xh * wh + xl * (wh * 2^-11) + xh * wl + (dropped: xl * wl * 2^-11, < 2^-22 |x w'|)
-// i.e. three MFMAs with the filter images wh, wh * 2^-11 (exact: a power-of-two scaling) and wl, all into ONE fp32 accumulator; the
+// i.e. three MFMAs with the filter operands wh, wh * 2^-11 (exact: a power-of-two scaling, formed in registers from the wh fragment with
+// four v_pk_mul_f16 -- one LDS image and a third of the filter bytes less than a stored copy) and wl, all into ONE fp32 accumulator; the
 // epilogue multiplies by 2^-S (exact).  Per-product error <= 3 * 2^-22 = 7e-7 relative, of random sign -- the level of the fp32
 // rounding of a K >= 288 dot product itself; measured against the float64 oracle in tests/test_gpu_ops.py (same 1e-5 bar as the
 // exact-fp32 kernels, errors reported next to the Winograd kernel's).  |x| must stay below 65504 (fp16 range): activations of
@@ -16,8 +17,8 @@
 // Kernel (the layout of conv_f16_w3.hip with fp32 tensors in HBM): block = 16 x 16 pixels x 64 couts, 4 waves; per 32-channel chunk
 // the raw 18 x 18 fp32 patch is loaded ONCE into registers (coalesced 128-byte lines, issued under the MFMAs of the previous
 // chunk), split, and written as two fp16 images of 64-byte rows (16-byte slot XOR-swizzled: conflict-free ds_read_b128); the three
-// filter images stream through LDS per tap (12 KB, register-staged one tap ahead, double-buffered).  Per tap and wave: 16 operand
-// reads feed 48 MFMAs.  66 KB of LDS, two blocks per CU.
+// two filter images stream through LDS per tap (8 KB, register-staged one tap ahead, double-buffered).  Per tap and wave: 16 operand
+// reads feed 48 MFMAs.  58 KB of LDS, two blocks per CU.
 // Fused around it: MaxPool2D(2) in the epilogue (the conv + max-pool pairs of hallucination_net.py:43-75 / vgg16.py:72-83: the 2 x 2
 // window is two accumulator rows of a lane and its neighbour lane) and tf.image.resize(x, 2x, BILINEAR) in the prologue (UP = true;
 // hallucination_net.py:86-88, dequantization_net.py:25-27): the block loads the 10 x 10 LOW-RES patch of a chunk (a quarter of the
@@ -38,7 +39,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int X3_HEADER_FLOATS = 16;                           // [0] max |w| (bits), [1] 2^-S; 64 bytes keep the images 16-byte aligned
 constexpr int BN = 64, NT = 4, MT = 4;
 constexpr int IMG_HALVES = BN * 32;                            // one filter image of a tap: [64 couts][32 channels]
-constexpr int UNIT_HALVES = 3 * IMG_HALVES;                    // wh, wh * 2^-11, wl
+constexpr int UNIT_HALVES = 2 * IMG_HALVES;                    // wh, wl
 constexpr int LRW = 10, LRPIX = LRW * LRW;                     // low-res patch of the up-sampling prologue
 constexpr int LRJ = (LRPIX * 8 + 255) / 256;                   // float4 pieces per thread (4)
 // KH x KW taps over a 16 x 16 output tile: raw patch (16 + KH - 1) x (16 + KW - 1).  3 x 3 = the stride-1 layers; 4 x 4, 4 x 3, 3 x 4
@@ -55,7 +56,7 @@ struct X3G {
 struct X3Args {
   const float* x1;
   const float* x2;
-  const _Float16* wp;      // packed [Cout / 64][units = Ct / 32 * 9][3 images][64][32]
+  const _Float16* wp;      // packed [Cout / 64][units = Ct / 32 * taps][2 images: wh, wl][64][32]
   const float* hdr;        // packed header: hdr[1] = 2^-S
   const float* bias;
   const float* scale;
@@ -205,24 +206,25 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     for (int j = 0; j < PJ; ++j)
       if (pdst[j] >= 0) split_store(pdst[j], pr[j]);
   };
-  // ---- filter units: 12 KB per tap = 768 pieces of 16 bytes, three per thread ---------------------------------------------------
+  // ---- filter units: 8 KB per tap = 512 pieces of 16 bytes, two per thread --------------------------------------------------------
+  constexpr int FJ = 2;
   const _Float16* wbase = a.wp + (size_t)pn * nunits * UNIT_HALVES;
-  int fdst[3];
+  int fdst[FJ];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < FJ; ++j) {
     const int p = tid + 256 * j;
     const int im = p >> 8, co = (p & 255) >> 2, slot = p & 3;
     fdst[j] = im * IMG_HALVES + co * 32 + 8 * (slot ^ f4(co));
   }
-  u32x4 fr[3];
+  u32x4 fr[FJ];
   auto load_filt = [&](int u) __attribute__((always_inline)) {
     const u32x4* g = reinterpret_cast<const u32x4*>(wbase + (size_t)u * UNIT_HALVES);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) fr[j] = g[tid + 256 * j];
+    for (int j = 0; j < FJ; ++j) fr[j] = g[tid + 256 * j];
   };
   auto store_filt = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(filt + buf * UNIT_HALVES + fdst[j]) = fr[j];
+    for (int j = 0; j < FJ; ++j) *reinterpret_cast<u32x4*>(filt + buf * UNIT_HALVES + fdst[j]) = fr[j];
   };
 
   f32x4 acc[MT][NT];
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         wh[ni] = *reinterpret_cast<const f16x8*>(F + b_rd[ni]);
-        ws[ni] = *reinterpret_cast<const f16x8*>(F + IMG_HALVES + b_rd[ni]);
-        wl[ni] = *reinterpret_cast<const f16x8*>(F + 2 * IMG_HALVES + b_rd[ni]);
+        wl[ni] = *reinterpret_cast<const f16x8*>(F + IMG_HALVES + b_rd[ni]);
+        ws[ni] = wh[ni] * (_Float16)(1.0f / 2048.0f);          // exact (power of two; gradual underflow below |wh| = 2^-3 as in fp16 itself)
       }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict_
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bit patterns
 }
-// packed[nb][u = chunk * 9 + tap][image][co][k]: w * x2-scale * 2^S split into wh, wh * 2^-11, wl
+// packed[nb][u = chunk * taps + tap][image][co][k]: w * x2-scale * 2^S split into wh, wl
 // taps of the packed filter = the sub-filter w[p0 + step * a][q0 + step * b], a < TH, b < TW, of a KWF-wide filter
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int Ct,
                                                       int C1, int Cout, float x2_scale, int KWF, int TH, int TW, int p0, int q0, int step) {
@@ -376,10 +378,9 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
     float v = w[((size_t)tap * Ct + ch) * Cout + nb * 64 + co] * s;
     if (ch >= C1) v *= x2_scale;
     const _Float16 h = (_Float16)v;
-    _Float16* o = out + ((size_t)(nb * nunits + u) * 3) * IMG_HALVES + co * 32 + k;
+    _Float16* o = out + ((size_t)(nb * nunits + u) * 2) * IMG_HALVES + co * 32 + k;
     o[0] = h;
-    o[IMG_HALVES] = (_Float16)((float)h * (1.0f / 2048.0f));
-    o[2 * IMG_HALVES] = (_Float16)(v - (float)h);
+    o[IMG_HALVES] = (_Float16)(v - (float)h);
   }
 }
 
@@ -401,7 +402,7 @@ int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
     for (int q0 = 0; q0 < 2; ++q0) ph[n++] = X3Phase{(d->KH - p0 + 1) / 2, (d->KW - q0 + 1) / 2, p0, q0, 2, p0 - d->pad_t, q0 - d->pad_l};
   return n;
 }
-inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + ((int64_t)3 * p.th * p.tw * Ct * Cout) / 2; }
+inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * Cout; }    // two fp16 images
 
 template <bool UP, int KH, int KW>
 int launch_x3(const X3Args& a, hipStream_t st) {
