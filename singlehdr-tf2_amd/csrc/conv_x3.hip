@@ -469,7 +469,9 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
   float* out = prepared;
   for (int i = 0; i < n; ++i) {
     if (hipMemsetAsync(out, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
-    hipLaunchKernelGGL(x3_absmax_kernel, dim3(shdr::stream_grid(nw)), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
+    // <= 64 blocks: every wave ends with an atomicMax on ONE address (2048 blocks took 50 us on a 9 MB filter, this takes 6)
+    const int gmax = shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64;
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(gmax), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
     const long np = (long)ph[i].th * ph[i].tw * Ct * d->Cout;
     hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
                        d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);
