@@ -75,7 +75,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
-__host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }
+__host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }      // filter images: rows = couts, 16-row aligned fragments
+// Patch images: the 16-byte slot of channel group kg of patch column c is kg ^ sx(c).  A ds_read_b128 is served in lane groups of
+// {8 lanes of one kg, 8 lanes of kg ^ 1}; with the lane -> tile-column permutation pcol() below each set of 8 reads 8 CONSECUTIVE
+// columns, so (column mod 8, kg) -- and with it (64-byte quarter, slot) -- is distinct for every tap shift: conflict-free at any
+// alignment (the row-keyed swizzle of the filter images 2-way-conflicted on 23 % of the LDS cycles here), and the address splits
+// into a per-lane column term (one register per kw) + a scalar row term: one VALU add per tap instead of six per operand read.
+__host__ __device__ inline int sx(int col) { return ((col >> 2) & 1) * 2; }
+__device__ __forceinline__ int pcol(int fi) { return fi < 4 ? fi : (fi >= 12 ? fi - 8 : fi + 4); }
 
 template <bool UP, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     const int ih = a.in_s * (oh0 + py) + a.bh, iw = a.in_s * (ow0 + px) + a.bw;
     const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
     ppix[j] = ok ? (img * a.Hin + ih) * a.Win + iw : -1;
-    pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1) : -1;
+    pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ sx(px)) + 4 * (q & 1) : -1;
   }
   // UP: low-res pieces of this thread: piece p = tid + 256 j -> (low-res patch pixel, float4)
   int lpix[LRJ];
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
           v[e] = t + (u - t) * wy;
         }
       }
-      split_store(pix * 32 + 8 * ((q >> 1) ^ f4(pix)) + 4 * (q & 1), v);
+      split_store(pix * 32 + 8 * ((q >> 1) ^ sx(px)) + 4 * (q & 1), v);
       if (j & 1) __builtin_amdgcn_sched_barrier(0);            // two pieces (32 registers of taps) in flight, not eleven: no spills
     }
   };
@@ -234,9 +241,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fg = lane >> 4;
-  int pix0[MT], b_rd[NT];
+  int acol[KW], b_rd[NT];                                      // A operand: half offset of (column pcol + kw, channel group fg) inside a patch row
+  const int pc = pcol(fi);
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) pix0[mi] = (wave * MT + mi) * PWID + fi;
+  for (int kw = 0; kw < KW; ++kw) acol[kw] = (pc + kw) * 32 + 8 * (fg ^ sx(pc + kw));
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     const int row = ni * 16 + fi;
@@ -255,35 +263,43 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) load_patch(c + 1);                        // lands under the taps of this chunk
 #pragma unroll 1
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      const int u = c * NTAPS + tap;
-      __syncthreads();                                         // unit u (and, at tap 0, the patch) is in LDS; buffer (u + 1) & 1 is free
-      if (u + 1 < nunits) load_filt(u + 1);
-      const int kh = tap / KW, kw = tap - KW * kh;
-      const _Float16* F = filt + (u & 1) * UNIT_HALVES;
-      f16x8 wh[NT], ws[NT], wl[NT], ph[MT], pl[MT];
+    for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) {
-        wh[ni] = *reinterpret_cast<const f16x8*>(F + b_rd[ni]);
-        wl[ni] = *reinterpret_cast<const f16x8*>(F + IMG_HALVES + b_rd[ni]);
-        ws[ni] = wh[ni] * (_Float16)(1.0f / 2048.0f);          // exact (power of two; gradual underflow below |wh| = 2^-3 as in fp16 itself)
-      }
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        const int pix = pix0[mi] + kh * PWID + kw;
-        const int o = pix * 32 + 8 * (fg ^ f4(pix));
-        ph[mi] = *reinterpret_cast<const f16x8*>(patch_h + o);
-        pl[mi] = *reinterpret_cast<const f16x8*>(patch_l + o);
-      }
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+      for (int kw = 0; kw < KW; ++kw) {                        // unrolled: acol[kw] stays a register
+        const int u = c * NTAPS + kh * KW + kw;
+        __syncthreads();                                       // unit u (and, at the first tap, the patch) is in LDS; buffer (u + 1) & 1 is free
+        if (u + 1 < nunits) load_filt(u + 1);
+        const _Float16* F = filt + (u & 1) * UNIT_HALVES;
+        const int rowh = (wave * MT + kh) * PWID * 32;          // scalar: first patch row of this wave and tap
+        // A-operand reads run one pixel row ahead of the MFMAs that use them
+        f16x8 wh[NT], ws[NT], wl[NT], ph[2], pl[2];
+        auto read_a = [&](int mi, int slot) __attribute__((always_inline)) {
+          const int o = rowh + mi * PWID * 32 + acol[kw];
+          ph[slot] = *reinterpret_cast<const f16x8*>(patch_h + o);
+          pl[slot] = *reinterpret_cast<const f16x8*>(patch_l + o);
+        };
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ph[mi], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[ni], pl[mi], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ph[mi], acc[mi][ni], 0, 0, 0);
+          wh[ni] = *reinterpret_cast<const f16x8*>(F + b_rd[ni]);
+          wl[ni] = *reinterpret_cast<const f16x8*>(F + IMG_HALVES + b_rd[ni]);
         }
-      if (u + 1 < nunits) store_filt((u + 1) & 1);             // read after the next barrier
+        read_a(0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) ws[ni] = wh[ni] * (_Float16)(1.0f / 2048.0f);      // exact (power of two; gradual underflow below |wh| = 2^-3 as in fp16 itself)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          if (mi + 1 < MT) read_a(mi + 1, (mi + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ph[mi & 1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[ni], pl[mi & 1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ph[mi & 1], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (u + 1 < nunits) store_filt((u + 1) & 1);           // read after the next barrier
+      }
     }
     if (c + 1 < nch) {
       if (UP) {
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts); the 2 x 2 pooling
   //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
   const float inv_s = a.hdr[1];
-  const int ow = ow0 + fi;
+  const int ow = ow0 + pc;                                     // the lane's tile column (pcol permutation)
 #pragma unroll
   for (int mp = 0; mp < MT / 2; ++mp) {
     const int oh = oh0 + wave * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
           m[e] = fmaxf(v[0][e], v[1][e]);
           m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
         }
-        if (!(fi & 1) && ow < a.W)
+        if (!(pc & 1) && ow < a.W)                               // lanes fi and fi ^ 1 hold columns pc and pc ^ 1
           *reinterpret_cast<f32x4*>(a.yp + ((size_t)(img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + n0 + cl) = m;
       }
     }
