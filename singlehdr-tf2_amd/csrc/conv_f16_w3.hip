@@ -35,7 +35,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
-__host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }
+__host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }      // filter image: rows = couts, 16-row aligned fragments
+// patch image: column-keyed slot swizzle + lane -> tile-column permutation (conv_x3.hip: a ds_read_b128 lane group = 8 lanes of one
+// channel group + 8 of its neighbour; with pcol() each set reads 8 consecutive columns -> conflict-free at every tap shift, and the
+// operand address is a per-lane column term + a scalar row term)
+__host__ __device__ inline int sx(int col) { return ((col >> 2) & 1) * 2; }
+__device__ __forceinline__ int pcol(int fi) { return fi < 4 ? fi : (fi >= 12 ? fi - 8 : fi + 4); }
 
 constexpr int PWID = 18, PPIX = PWID * PWID;                   // raw patch of a 16 x 16 tile
 constexpr int PJ = 6;                                          // patch DMA instructions per wave (24 x 64 pieces >= 1296)
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
     const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
     pok[j] = pix < PPIX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     const unsigned p = pok[j] ? (unsigned)((img * a.H + ih) * a.W + iw) : 0u;
-    const unsigned kg = (unsigned)(slot ^ f4(pix));
+    const unsigned kg = (unsigned)(slot ^ sx(px));
     poff1[j] = p * (unsigned)a.C1 + 8u * kg;
     poff2[j] = p * (unsigned)a.C2 + 8u * kg;
   }
@@ -112,9 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fg = lane >> 4;
-  int pix0[MT], b_rd[NT];
+  int acol[3], b_rd[NT];
+  const int pc = pcol(fi);
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) pix0[mi] = (wave * MT + mi) * PWID + fi;
+  for (int kw = 0; kw < 3; ++kw) acol[kw] = (pc + kw) * 32 + 8 * (fg ^ sx(pc + kw));
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     const int row = ni * 16 + fi;
@@ -139,10 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) wb[ni] = *reinterpret_cast<const f16x8*>(F + kw * BN * 32 + b_rd[ni]);
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        const int pix = pix0[mi] + kh * PWID + kw;
-        pa[mi] = *reinterpret_cast<const f16x8*>(P + pix * 32 + 8 * (fg ^ f4(pix)));
-      }
+      for (int mi = 0; mi < MT; ++mi) pa[mi] = *reinterpret_cast<const f16x8*>(P + ((wave * MT + mi + kh) * PWID) * 32 + acol[kw]);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
   _Float16* stage = wsm;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
-    const int r = (wave * MT + mi) * 16 + fi;
+    const int r = (wave * MT + mi) * 16 + pc;                    // the lane's tile column (pcol permutation)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int cl = ni * 16 + 4 * fg;
