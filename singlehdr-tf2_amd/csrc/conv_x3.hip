@@ -410,7 +410,7 @@ struct X3Phase { int th, tw, p0, q0, step, bh, bw; };
 // the 4 x 4, 4 x 3, 3 x 4 and 3 x 3 sub-filters -- exactly the 49 taps, each phase one launch accumulating into y.
 int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
   if (d->stride == 1) {
-    ph[0] = X3Phase{3, 3, 0, 0, 1, -d->pad_t, -d->pad_l};
+    ph[0] = X3Phase{d->KH, d->KW, 0, 0, 1, -d->pad_t, -d->pad_l};        // 3 x 3 (pad 1) or 1 x 1 (pad 0): all taps in one launch
     return 1;
   }
   int n = 0;
@@ -445,7 +445,12 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
   if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
   if (getenv("SHDR_NO_X3")) return 0;
   if (d->stride == 1) {
-    if (d->KH != 3 || d->KW != 3 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad_t == 1 && d->pad_l == 1;
+    // 1 x 1 layers (the skip layers of hallucination_net.py:93-107 on tf.concat of two sources, the bottleneck convs of the ResNet
+    // blocks): one tap per chunk, so the patch split is not amortised over nine taps -- still 2-3x the fp32-MFMA kernel from K = 256 on
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && d->prologue == SHDR_PROLOGUE_NONE &&
+                    getenv("SHDR_NO_X3_1X1") == nullptr;
+    if (!(k3 || k1) || d->Ho != d->H || d->Wo != d->W) return 0;
   } else {
     // the 7 x 7 / stride-2 stem with TF SAME padding (one source, no prologue)
     int ho = 0, wo = 0, pt = 0, pl = 0;
@@ -534,6 +539,7 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
     a.final = i == n - 1;
     int rc;
     if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
+    else if (ph[i].th == 1 && ph[i].tw == 1) rc = launch_x3<false, 1, 1>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 4) rc = launch_x3<false, 4, 4>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 3) rc = launch_x3<false, 4, 3>(a, st);
     else if (ph[i].th == 3 && ph[i].tw == 4) rc = launch_x3<false, 3, 4>(a, st);

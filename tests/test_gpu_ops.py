@@ -424,6 +424,28 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     assert torch.equal(K.conv2d(dev(x), dev(wt), None, act1=K.ACT_RELU), y)
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128)])
+def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
+    """1x1 layers with K >= 256 on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet
+    bottleneck convs): one tap per chunk; vs the float64 oracle at the exact-fp32 bar, ragged tiles"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, c1, c2, cout = shape
+    rng = np.random.default_rng(sum(shape) + 9)
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, c1)))
+    x2 = f32(rng.normal(size=(n, h, w, c2)) * 255.0) if c2 else None
+    x2s = 1.0 / 255 if c2 else 1.0
+    wt = f32(rng.normal(size=(1, 1, c1 + c2, cout)) / np.sqrt(c1 + c2))
+    b, sc, sh = f32(rng.normal(size=cout)), f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=x2s) == "x3"
+    ref = oracle_conv(x, wt, b, x2=x2, x2_scale=x2s, act1=1, scale=sc, shift=sh, act2=1)
+    y = K.conv2d(dev(x), dev(wt), dev(b), x2=None if x2 is None else dev(x2), x2_scale=x2s, act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh),
+                 act2=K.ACT_RELU)
+    assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
+    # with a fused residual the layer stays on the exact-fp32 kernel (the split kernel's epilogue has none)
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=x2s, has_residual=True) == "mfma"
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96, 96, 64), (1, 61, 75, 96, 64), (1, 32, 34, 32, 128), (1, 17, 16, 64, 64)])
 def test_conv2d_x3_stride2_stem_as_four_phases(shdr, shape, monkeypatch):
     """the 7x7 / stride-2 stem of the Linearization-Net (linearization_net.py:91) on the split-operand kernel: four stride-1 phase
