@@ -110,7 +110,10 @@ typedef struct shdr_conv2d_desc {
    * every other plan materialises it in the workspace (shdr_conv2d_workspace_bytes_f32 accounts for it). */
   int32_t prologue;
 } shdr_conv2d_desc;
-enum { SHDR_PROLOGUE_NONE = 0, SHDR_PROLOGUE_BILINEAR2X = 1 };
+enum { SHDR_PROLOGUE_NONE = 0, SHDR_PROLOGUE_BILINEAR2X = 1,
+       /* split-operand kernel only (shdr_conv2d_fwd_x3_f32): x1 is scaled in the kernel by the power of two that brings max |x1| -- written
+        * into the prepared filter's header by shdr_conv2d_x3_input_absmax_f32 -- into the fp16 range; for inputs far below it (gradients) */
+       SHDR_PROLOGUE_RANGE_SCALE = 2 };
 
 int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
                         const float* x1, const float* x2, const float* w,
@@ -380,6 +383,8 @@ int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const flo
 int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d);
 int64_t shdr_conv2d_x3_filter_elems_f32(const shdr_conv2d_desc* d);
 int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream);
+/* max |x| over n floats -> header of `prepared` (after shdr_conv2d_x3_prepare_filter_f32, before the SHDR_PROLOGUE_RANGE_SCALE launch) */
+int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                            const float* scale, const float* shift, float* y, float* y_pool, void* stream);
 

@@ -279,6 +279,9 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
       if (int rc = shdr_conv2d_x3_prepare_filter_f32(&c, wt, u, stream)) return rc;
+      // output gradients sit far below the fp16 range (max |dz| 3e-8 ... 2e-2 in the joint step): scaled in the kernel by a power of two
+      if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;
+      c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
       return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, stream);
     }
     if (g.wino) {

@@ -84,7 +84,11 @@ __host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }      //
 __host__ __device__ inline int sx(int col) { return ((col >> 2) & 1) * 2; }
 __device__ __forceinline__ int pcol(int fi) { return fi < 4 ? fi : (fi >= 12 ? fi - 8 : fi + 4); }
 
-template <bool UP, int KH, int KW>
+// RS = true: the input is multiplied by the power of two that brings max |x| (hdr[2], device-resident, written by
+// shdr_conv2d_x3_input_absmax_f32) to [2^10, 2^11) before the split and the result divided by it -- both exact.  For inputs far below
+// the fp16 range: the output gradients dz of the training steps (max |dz| 3e-8 ... 2e-2 in the joint step: unscaled, their high terms
+// are fp16 subnormals and the parameter gradient differed from the exact-fp32 kernels' by 3e-5; scaled, by the run-to-run noise).
+template <bool UP, int KH, int KW, bool RS = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   using G = X3G<KH, KW>;
   constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, PATCH_HALVES = G::PATCH_HALVES, NTAPS = KH * KW;
@@ -149,11 +153,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     for (int j = 0; j < LRJ; ++j)
       if (tid + 256 * j < LRPIX * 8) *reinterpret_cast<f32x4*>(lrs + 4 * (tid + 256 * j)) = pr[j];
   };
+  float xs = 1.0f, ixs = 1.0f;                                 // RS: input scale 2^T and its inverse
+  if (RS) {
+    const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(a.hdr)[2]);
+    if (mx > 0.0f) {
+      int ex;
+      frexpf(mx, &ex);                                         // mx in [2^(ex-1), 2^ex)
+      int T = 11 - ex;
+      T = T < -100 ? -100 : (T > 100 ? 100 : T);
+      xs = ldexpf(1.0f, T);
+      ixs = ldexpf(1.0f, -T);
+    }
+  }
   auto split_store = [&](int dst, const f32x4 v4) __attribute__((always_inline)) {            // one float4 -> 8 bytes in each fp16 image
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v = v4[e];
+      const float v = RS ? v4[e] * xs : v4[e];
       h[e] = (_Float16)v;
       l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
     }
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 
   // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts); the 2 x 2 pooling
   //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
-  const float inv_s = a.hdr[1];
+  const float inv_s = a.hdr[1] * ixs;
   const int ow = ow0 + pc;                                     // the lane's tile column (pcol permutation)
 #pragma unroll
   for (int mp = 0; mp < MT / 2; ++mp) {
@@ -369,6 +385,20 @@ __global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict_
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bit patterns
 }
+// max |x| of a large tensor into *out (block-level reduction, one atomicMax per block)
+__global__ __launch_bounds__(256) void x3_absmax_big_kernel(const float* __restrict__ x, long n4, unsigned* __restrict__ out) {
+  __shared__ float part[4];
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
 // packed[nb][u = chunk * taps + tap][image][co][k]: w * x2-scale * 2^S split into wh, wl
 // taps of the packed filter = the sub-filter w[p0 + step * a][q0 + step * b], a < TH, b < TW, of a KWF-wide filter
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int Ct,
@@ -420,19 +450,19 @@ int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
 }
 inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * Cout; }    // two fp16 images
 
-template <bool UP, int KH, int KW>
+template <bool UP, int KH, int KW, bool RS = false>
 int launch_x3(const X3Args& a, hipStream_t st) {
   constexpr int lds = UP ? X3G<KH, KW>::LDS_BYTES_UP : X3G<KH, KW>::LDS_BYTES;
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW, RS>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_x3_kernel");
 }
 
@@ -501,13 +531,24 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
   return shdr::check_launch("conv2d_x3_prepare_filter");
 }
 
+extern "C" int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float* prepared, void* stream) {
+  SHDR_REQUIRE(x && prepared, SHDR_E_NULL, "conv2d_x3_input_absmax: null pointer");
+  SHDR_REQUIRE(n > 0 && n % 4 == 0 && shdr::aligned16(x), SHDR_E_SHAPE, "conv2d_x3_input_absmax: n must be a positive multiple of 4, x 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = shdr::stream_grid(n / 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(x3_absmax_big_kernel, dim3(grid), dim3(256), 0, st, x, (long)(n / 4), reinterpret_cast<unsigned*>(prepared) + 2);
+  return shdr::check_launch("conv2d_x3_input_absmax");
+}
+
 extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                       const float* scale, const float* shift, float* y, float* y_pool, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or neither y nor y_pool");
   SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even Ho, Wo");
-  const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X;
-  SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || (up && d->stride == 1 && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
+  const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X, rs = d->prologue == SHDR_PROLOGUE_RANGE_SCALE;
+  SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || rs || (up && d->stride == 1 && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
                "conv2d_x3: the bilinear 2x prologue takes a stride-1 layer, one source and even (up-sampled) H, W");
+  SHDR_REQUIRE(!rs || (d->stride == 1 && d->KH == 3 && d->C2 == 0), SHDR_E_SHAPE, "conv2d_x3: the range-scale prologue is built for one-source 3x3 layers");
   SHDR_REQUIRE(shdr_conv2d_x3_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3: layer shape not taken by this kernel");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3: x2 must be given iff C2 > 0");
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3: scale and shift come together");
@@ -538,7 +579,8 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
     a.yin = i > 0 ? y : nullptr;
     a.final = i == n - 1;
     int rc;
-    if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
+    if (ph[i].th == 3 && ph[i].tw == 3 && rs) rc = launch_x3<false, 3, 3, true>(a, st);
+    else if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
     else if (ph[i].th == 1 && ph[i].tw == 1) rc = launch_x3<false, 1, 1>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 4) rc = launch_x3<false, 4, 4>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 3) rc = launch_x3<false, 4, 3>(a, st);
