@@ -492,7 +492,7 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
   }
   // enough blocks to fill the chip: the deepest, smallest maps stay on the fused Winograd kernel (8 x 16 tiles)
   const long blocks = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 64);
-  long min_blocks = 384;
+  long min_blocks = 192;          // measured (tools/dbg/x3_threshold.py): 256 blocks 1.24-1.28x the fused Winograd kernel, 128 blocks 0.75x
   if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
   return blocks >= min_blocks ? 1 : 0;
 }

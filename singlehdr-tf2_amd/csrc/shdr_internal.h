@@ -54,20 +54,32 @@ inline int stream_grid(int64_t work_items, int block = 256) {
 }
 
 // out[c] += sum over the g partial rows ws[b * C + c] (written by reduction kernels that give every block its own row instead
-// of ending in atomics on the same C addresses).  Block = 64 columns x 4 row lanes, blockIdx.y = row slice of <= 256 rows.
+// of ending in atomics on the same C addresses).  Block = 16 columns x 16 row lanes, four independent loads in flight per thread
+// (64 columns x 4 row lanes with one dependent load chain per thread took 43 us on 2048 rows: latency-bound), blockIdx.y = row slice.
 __global__ __launch_bounds__(256) static void col_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int g, int C) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  __shared__ float part[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const int r0 = blockIdx.y * 256, r1 = r0 + 256 < g ? r0 + 256 : g;
-  float t = 0.f;
-  if (c < C)
-    for (int r = r0 + rl; r < r1; r += 4) t += ws[(size_t)r * C + c];
-  part[rl][threadIdx.x & 63] = t;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (c < C) {
+    int r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+      t0 += ws[(size_t)r * C + c]; t1 += ws[(size_t)(r + 16) * C + c]; t2 += ws[(size_t)(r + 32) * C + c]; t3 += ws[(size_t)(r + 48) * C + c];
+    }
+    for (; r < r1; r += 16) t0 += ws[(size_t)r * C + c];
+  }
+  part[rl][cl] = (t0 + t1) + (t2 + t3);
   __syncthreads();
-  if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][cl];
+    atomicAdd(out + c, t);
+  }
 }
 inline void launch_col_fold(const float* ws, float* out, int g, int C, hipStream_t st) {
-  hipLaunchKernelGGL(col_fold_kernel, dim3((C + 63) / 64, (g + 255) / 256), dim3(256), 0, st, ws, out, g, C);
+  hipLaunchKernelGGL(col_fold_kernel, dim3((C + 15) / 16, (g + 255) / 256), dim3(256), 0, st, ws, out, g, C);
 }
 constexpr int kBiasMaxBlocks = 2048;          // rows of the act_bwd_bias workspace (shdr_workspace_bytes(SHDR_OP_ACT_BWD_BIAS))
 
