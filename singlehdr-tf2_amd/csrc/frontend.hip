@@ -15,6 +15,8 @@
 #include "shdr_internal.h"
 
 namespace {
+typedef float nt4 __attribute__((ext_vector_type(4)));       // for __builtin_nontemporal_store
+
 
 __device__ __forceinline__ float soft_bin(float x, int i /*1..B*/, float two_b, float nb, float thr) {
 #pragma clang fp contract(off)  // this file is also built with -ffp-contract=off
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void soft_hist_rows_kernel(const float* __rest
       const float d = fabsf(__fsub_rn(xv[k], centre[k]));
       v[k] = d < thr ? __fsub_rn(1.0f, __fmul_rn(d, nb)) : 0.0f;
     }
-    *reinterpret_cast<float4*>(y + (p * Q + q) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    __builtin_nontemporal_store((nt4){v[0], v[1], v[2], v[3]}, reinterpret_cast<nt4*>(y + (p * Q + q) * 4));      // written once, read by another kernel
   };
   long p = t / Q;
   for (; p + 3 * dp < npix; p += 4 * dp) {                  // four pixels in flight
@@ -198,24 +200,30 @@ __global__ __launch_bounds__(256) void lin_frontend_rows_kernel(const float* __r
     t[93] = 0.0f; t[94] = 0.0f; t[95] = 0.0f;
   }
   __syncthreads();
-  // histogram channels 9 .. 92: 84 per pixel, 5376 per block, 21 per thread; consecutive threads = consecutive channels
-  for (int e = tid; e < PX * 84; e += 256) {
-    const int px = e / 84, k = e - px * 84;           // k: 0..11 -> B = 4, 12..35 -> B = 8, 36..83 -> B = 16
+  // histogram channels 9 .. 92: 84 per pixel.  Thread = (pixel phase g of 3, channel k): the channel's bin centre, bin count and
+  // colour index are computed ONCE per thread (the element-major loop spent 25 VALU operations per value on e / 84, idx / 3 and
+  // the level select: the kernel was VALU-bound at 4.3 TB/s); consecutive threads = consecutive channels of one pixel
+  if (tid < 252) {
+    const int g = tid / 84, k = tid - g * 84;         // k: 0..11 -> B = 4, 12..35 -> B = 8, 36..83 -> B = 16
     const int lvl = k < 12 ? 0 : (k < 36 ? 1 : 2);
     const int idx = k - (lvl == 0 ? 0 : (lvl == 1 ? 12 : 36));
     const int B = 4 << lvl;
     const int bin = idx / 3, c = idx - bin * 3;
     // 1/(2B) is a power of two: (2i-1) * (1/(2B)) is the correctly rounded quotient of soft_bin's IEEE divide
     const float centre = (float)(2 * bin + 1) * (0.5f / (float)B);
-    const float d = fabsf(__fsub_rn(rgbs[px * 3 + c], centre));
-    tile[px * 96 + 9 + k] = d < 1.0f / (float)B ? __fsub_rn(1.0f, __fmul_rn(d, (float)B)) : 0.0f;
+    const float fB = (float)B, w = 1.0f / fB;
+#pragma unroll 4
+    for (int px = g; px < PX; px += 3) {
+      const float d = fabsf(__fsub_rn(rgbs[px * 3 + c], centre));
+      tile[px * 96 + 9 + k] = d < w ? __fsub_rn(1.0f, __fmul_rn(d, fB)) : 0.0f;
+    }
   }
   __syncthreads();
   const int npx = min(PX, W - w0);
   float* yo = y + (ibase + (long)h * W + w0) * YC;
   if (YC == 96) {
     const int nq = npx * 24;
-    for (int q = tid; q < nq; q += 256) *reinterpret_cast<float4*>(yo + 4 * q) = *reinterpret_cast<const float4*>(tile + 4 * q);
+    for (int q = tid; q < nq; q += 256) __builtin_nontemporal_store(*reinterpret_cast<const nt4*>(tile + 4 * q), reinterpret_cast<nt4*>(yo + 4 * q));
   } else {
     const int n = npx * 93;
     for (int e = tid; e < n; e += 256) yo[e] = tile[(e / 93) * 96 + e % 93];
