@@ -134,12 +134,34 @@ class model(Layer):
         x = self.s4(self.u4(x, training), d4)
         x = self.s3(self.u3(x, training), d3)
         x = self.s2(self.u2(x, training), d2)
-        x = self.s1(self.u1(x, training), d1)
-        if train:
-            x = self.norm2.train_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
-        elif frozen:
-            x = self.norm2.frozen_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
+        if train or frozen:
+            x = self.s1(self.u1(x, training), d1)
+            if train:
+                x = self.norm2.train_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
+            else:
+                x = self.norm2.frozen_apply(self.conv2.call_padded(x, cout_pad=16), relu=True)
         else:
+            # inference: s1 (1x1 on concat[u1, d1 / 255], no activation: hallucination_net.py:179) and conv2 (1x1, :183) are two
+            # linear maps in a row -- ONE 1x1 convolution 64 + 64 -> 3 with the composed filter W1 W2 and bias b1 W2 + b2 (a 128 x 3
+            # matrix, composed in float64 once per parameter version).  The 64-channel full-resolution tensor between them (1 GB
+            # written and read back at 16 x 512^2) never exists.
             sc, sh = self.norm2.folded()
-            x = self.conv2.call_padded(x, cout_pad=16, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:183-185)
+            wc, bc = self._tail_filter(d1.shape[-1])
+            x = K.conv2d(self.u1(x, training), wc, bc, x2=d1, cout_valid=3, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:179-185)
         return self.s0(x, bgr, act1=K.ACT_RELU)                    # relu(s0(x, bgr)) (:188-190)
+
+    def _tail_filter(self, c_skip):
+        """composed 1x1 filter [1,1,64 + c_skip,16] (3 real output channels) and bias [3] of s1 -> conv2; the skip rows carry the 1/255"""
+        k1, b1, k2, b2 = self.s1.conv1.kernel, self.s1.conv1.bias, self.conv2.kernel, self.conv2.bias
+        key = (k1._version, b1._version, k2._version, b2._version, c_skip)
+        if getattr(self, "_tail", None) is None or self._tail[0] != key:
+            with torch.no_grad():
+                w1 = k1.detach().double().reshape(k1.shape[2], k1.shape[3]).clone()      # [128, 64]
+                w1[w1.shape[0] - c_skip:] *= 1.0 / 255
+                w2 = k2.detach().double().reshape(k2.shape[2], k2.shape[3])              # [64, 3]
+                wc = torch.zeros((1, 1, w1.shape[0], 16), device=k1.device, dtype=torch.float32)
+                wc[0, 0, :, :3] = (w1 @ w2).float()
+                bc = (b1.detach().double() @ w2 + b2.detach().double()).float().contiguous()
+                wc._shdr_const = True
+            self._tail = (key, wc, bc)
+        return self._tail[1], self._tail[2]
