@@ -127,8 +127,9 @@ enum {
   SHDR_PLAN_MFMA = 1,             /* implicit GEMM: LDS-DMA / register-staged / register-A kernel, chosen by shape    */
   SHDR_PLAN_WINOGRAD_FUSED = 2,   /* one-kernel Winograd F(2x2,3x3) (3x3 stride 1 SAME, Cin % 8 == 0, Cout % 64 == 0) */
   SHDR_PLAN_WINOGRAD_PLANES = 3,  /* three-kernel Winograd for wide layers whose Cout is not a multiple of 64         */
-  SHDR_PLAN_X3 = 4                /* 3x3 stride 1, C % 32 == 0 per source, Cout % 64 == 0, enough tiles to fill the chip: fp32 operands split
+  SHDR_PLAN_X3 = 4,               /* 3x3 stride 1, C % 32 == 0 per source, Cout % 64 == 0, enough tiles to fill the chip: fp32 operands split
                                      into two fp16 terms, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation (conv_x3.hip) */
+  SHDR_PLAN_X3N = 5               /* the same arithmetic for the narrow layers (Cout 16 / 32, <= 32 channels per tap; conv_x3n.hip) */
 };
 int shdr_conv2d_plan_f32(const shdr_conv2d_desc* d, int has_residual);
 /* The prepared form of the HWIO filter `w` for that plan: the packed Winograd transform U = G g G^T, or the plain filter with
@@ -387,6 +388,17 @@ int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w,
 int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                            const float* scale, const float* shift, float* y, float* y_pool, void* stream);
+
+/* The split-operand arithmetic for the NARROW layers (SHDR_PLAN_X3N; csrc/conv_x3n.hip): stride 1, 3x3 / 5x5 / 7x7 SAME, Cout 16 or 32
+ * (cout_valid <= Cout stored), one source of 4 ... 32 channels (C1 % 4 == 0) or two of 16 -- the full-resolution layers of the
+ * Dequantization- / Refinement-Net U-Nets (dequantization_net.py:8-63).  Whole filter + raw patch in LDS, persistent blocks.
+ * y = act2(affine(act1(conv + bias)) + residual).  prepared: shdr_conv2d_x3n_filter_elems_f32 floats from
+ * shdr_conv2d_x3n_prepare_filter_f32 (w: HWIO with the descriptor's Cout columns).  Reached through shdr_conv2d_fwd_prepared_f32. */
+int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d);
+int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d);
+int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream);
+int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                            const float* scale, const float* shift, const float* residual, float* y, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

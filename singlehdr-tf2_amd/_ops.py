@@ -275,7 +275,7 @@ def _prepared_filter(lib, w, d, has_res):
     return prepared
 
 
-_PLAN_NAMES = {0: "direct", 1: "mfma", 2: "fused", 3: "planes", 4: "x3"}
+_PLAN_NAMES = {0: "direct", 1: "mfma", 2: "fused", 3: "planes", 4: "x3", 5: "x3n"}
 
 
 def conv2d_plan(x_shape, w_shape, c2=0, stride=1, x2_scale=1.0, has_residual=False, cout_valid=None):

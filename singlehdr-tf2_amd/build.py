@@ -22,6 +22,7 @@ SOURCES = {
     "conv.hip": [],
     "conv_plan.hip": [],
     "conv_x3.hip": [],
+    "conv_x3n.hip": [],
     "conv_f16.hip": [],
     "conv_f16_patch.hip": [],
     "conv_f16_w3.hip": [],

@@ -33,6 +33,9 @@ int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   const bool same = d->pad_t == pt && d->pad_l == pl && d->Ho == ho && d->Wo == wo;
   const bool wino_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && same && !has_residual && cout_valid == d->Cout &&
                           d->w_batch_stride == 0 && d->y_pix_stride <= 1 && getenv("SHDR_NO_WINOGRAD") == nullptr;
+  // the narrow layers of the U-Nets (Cout 16 / 32, <= 32 channels per tap): the split-operand arithmetic with the whole filter in LDS;
+  // its epilogue takes a residual
+  if (d->algo == SHDR_ALGO_AUTO && same && getenv("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3n_ok_f32(d)) return SHDR_PLAN_X3N;
   // the split-operand fp16 kernel first (1.4-1.5x the fused Winograd kernel's rate, same accuracy class; also the 7x7 / 2 stem);
   // SHDR_ALGO_AUTO_EXACT opts out
   if (d->algo == SHDR_ALGO_AUTO && !has_residual && same && getenv("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
@@ -141,6 +144,7 @@ extern "C" int64_t shdr_conv2d_prepared_filter_elems_f32(const shdr_conv2d_desc*
   const int plan = plan_of(d, has_residual != 0);
   const int64_t Ct = d->C1 + d->C2;
   if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_filter_elems_f32(d);
+  if (plan == SHDR_PLAN_X3N) return shdr_conv2d_x3n_filter_elems_f32(d);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED || plan == SHDR_PLAN_WINOGRAD_PLANES) return 16 * Ct * d->Cout;
   return (int64_t)d->KH * d->KW * Ct * d->Cout;
 }
@@ -150,6 +154,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
   const int plan = plan_of(d, has_residual != 0);
   const int Ct = d->C1 + d->C2;
   if (plan == SHDR_PLAN_X3) return shdr_conv2d_x3_prepare_filter_f32(d, w, prepared, stream);
+  if (plan == SHDR_PLAN_X3N) return shdr_conv2d_x3n_prepare_filter_f32(d, w, prepared, stream);
   if (plan == SHDR_PLAN_WINOGRAD_FUSED) return shdr_winograd_filter_packed_f32(w, prepared, Ct, d->Cout, stream);
   if (plan == SHDR_PLAN_WINOGRAD_PLANES) return shdr_winograd_filter_f32(w, prepared, Ct, d->Cout, stream);
   const long total = (long)d->KH * d->KW * Ct * d->Cout;
@@ -215,7 +220,9 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, stream);
   SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd and split-operand paths");
   int rc;
-  if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
+  if (plan == SHDR_PLAN_X3N) {
+    rc = shdr_conv2d_fwd_x3n_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, stream);
+  } else if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
     SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
     const int Cin = d->C1;
     const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);

@@ -1,0 +1,411 @@
+// Narrow fp32 convolutions on the fp16 matrix pipe (the split-operand arithmetic of conv_x3.hip: x = xh + xl 2^-11, w 2^S = wh + wl,
+// x w = xh wh + xl (wh 2^-11) + xh wl, fp32 accumulation) for the full-resolution layers of the Dequantization- / Refinement-Net
+// U-Nets (dequantization_net.py:8-9,21-22,27,35-36,46,62-63, refinement_net.py): 7x7 3(4) -> 16 and 16 -> 16, 5x5 16 -> 32 and
+// 32 -> 32, 3x3 32 -> 16, 16 + 16 -> 16 (tf.concat), 16 -> 3 (tanh + residual).  With 16 couts every activation value feeds ONE
+// MFMA column block: the exact-fp32 kernels are bound by the fp32 matrix pipe or by their operand feed (54-105 TFLOP/s).
+//
+// Layout of conv_f16_patch.hip with fp32 tensors in HBM: persistent blocks keep the WHOLE filter (two fp16 images, k in the natural
+// (tap, channel) order) in LDS; per 16 x 16 pixel tile the raw fp32 patch (+ halo) is loaded into registers under the MFMAs of the
+// previous tile, split, and written as two fp16 patch images; the MFMA operand of a lane -- 8 consecutive channels of one pixel at
+// one tap -- is read straight from the patch at the tap's offset (one v_mfma_f32_16x16x32_f16 covers 32 / CT taps).  Epilogue:
+// y = act1(acc 2^-S + bias) + residual, fp32, only the first cout_valid channels stored.
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+#include "shdr_internal.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int XN_HEADER_FLOATS = 16;                            // [0] max |w| (bits), [1] 2^-S
+
+struct X3nArgs {
+  const float* x1;
+  const float* x2;
+  const _Float16* wp;      // packed [2 images: wh, wl][nsteps][COUT][32], natural k order
+  const float* hdr;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* res;        // residual [N,H,W,res_cs] (or null)
+  float* y;                // [N,H,W,cout_valid]
+  int N, H, W, C1, tiles_x, tiles_y, ntiles, act1, act2, cout_valid, res_cs;
+};
+
+__host__ __device__ inline int pswz(int row) { return (-(row >> 2)) & 3; }
+
+template <int KK, int CT, int NT, bool TWO>
+struct NG {
+  static constexpr int TPP = 32 / CT;                          // taps per MFMA k-step
+  static constexpr int NTAPS = KK * KK;
+  static constexpr int NS = (NTAPS + TPP - 1) / TPP;           // k-steps
+  static constexpr int PW = 16 + KK - 1, PH = 16 + KK - 1;
+  static constexpr int PP = PW * PH;                           // patch pixels
+  static constexpr int PIECES = PP * CT / 4;                   // float4 pieces of the patch (both sources)
+  static constexpr int PJ = (PIECES + 255) / 256;              // per thread
+  static constexpr int PATCH_HALVES = PP * CT;                 // one fp16 image
+  static constexpr int COUT = NT * 16;
+  static constexpr int FILT_HALVES = NS * COUT * 32;           // one image
+  static constexpr int FINSTR = 2 * NS * COUT / 16;            // filter DMA instructions, both images (16 rows of 64 bytes each)
+  static constexpr int LDS_BYTES = (2 * FILT_HALVES + 2 * PATCH_HALVES) * 2;
+};
+
+template <int KK, int CT, int NT, bool TWO>
+__global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
+  using G = NG<KK, CT, NT, TWO>;
+  constexpr int MT = 4;                                        // wave w owns tile rows 4w .. 4w+3
+  constexpr int PAD = (KK - 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) _Float16 nsm[];
+#define filt_h (nsm)                                           /* [NS][COUT][32], swizzled rows */
+#define filt_l (nsm + G::FILT_HALVES)
+#define patch_h (nsm + 2 * G::FILT_HALVES)                     /* [PP][CT] (TWO: [source][PP][16]) */
+#define patch_l (nsm + 2 * G::FILT_HALVES + G::PATCH_HALVES)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- both filter images -> LDS, once per block (rows of 64 bytes, physical slot = k-group ^ swz(cout)) ---------------------------
+  for (int j = wave; j < G::FINSTR; j += 4) {
+    const int r = j * 16 + (lane >> 2);                        // row = (image * NS + step) * COUT + cout
+    const int co = r % G::COUT;
+    const _Float16* p = a.wp + (size_t)r * 32 + 8 * ((lane & 3) ^ pswz(co));
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(nsm + j * 512), 16, 0, 0);
+  }
+
+  // ---- patch geometry: piece = tid + 256 j -> (source, patch pixel, float4 of the pixel), fixed over the tiles ---------------------
+  int ppy[G::PJ], ppx[G::PJ], pdst[G::PJ], pch[G::PJ];        // pch: channel offset in the source tensor, -1: zero padding channels / no piece
+#pragma unroll
+  for (int j = 0; j < G::PJ; ++j) {
+    const int piece = tid + 256 * j;
+    int pix, c4, src = 0;
+    if (TWO) {                                                 // image [source][pixel][16 channels]
+      src = piece / (G::PP * 4);
+      const int rem = piece - src * G::PP * 4;
+      pix = rem >> 2;
+      c4 = rem & 3;
+    } else {
+      pix = piece / (CT / 4);
+      c4 = piece - pix * (CT / 4);
+    }
+    ppy[j] = pix / G::PW;
+    ppx[j] = pix - ppy[j] * G::PW;
+    const bool ok = piece < G::PIECES;
+    if (TWO) {
+      pdst[j] = ok ? src * G::PP * 16 + pix * 16 + 4 * c4 : -1;
+      pch[j] = ok ? (src << 16) | (4 * c4) : -1;
+    } else {
+      const int cg = (CT == 32) ? ((c4 >> 1) ^ pswz(pix)) : (c4 >> 1);       // 64-byte pixels: the b128 bank swizzle
+      pdst[j] = ok ? pix * CT + 8 * cg + 4 * (c4 & 1) : -1;
+      pch[j] = (ok && 4 * c4 < a.C1) ? 4 * c4 : -1;            // channels beyond the source's (3 -> 4, 9 -> 12 padded inputs) are zero
+    }
+  }
+  f32x4 pr[G::PJ];
+  auto load_patch = [&](int tile) __attribute__((always_inline)) {
+    int pm = tile;
+    const int tx = pm % a.tiles_x;
+    pm /= a.tiles_x;
+    const int ty = pm % a.tiles_y;
+    const int img = pm / a.tiles_y;
+    const int ih0 = ty * 16 - PAD, iw0 = tx * 16 - PAD;
+#pragma unroll
+    for (int j = 0; j < G::PJ; ++j) {
+      const int ih = ih0 + ppy[j], iw = iw0 + ppx[j];
+      pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pch[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+        const float* src = (TWO && (pch[j] >> 16)) ? a.x2 : a.x1;
+        const int cs = TWO ? 16 : a.C1;
+        pr[j] = *reinterpret_cast<const f32x4*>(src + ((size_t)(img * a.H + ih) * a.W + iw) * cs + (pch[j] & 0xFFFF));
+      }
+    }
+  };
+  auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < G::PJ; ++j) {
+      if (pdst[j] < 0) continue;
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = pr[j][e];
+        h[e] = (_Float16)v;
+        l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
+      }
+      *reinterpret_cast<f16x4*>(patch_h + pdst[j]) = h;
+      *reinterpret_cast<f16x4*>(patch_l + pdst[j]) = l;
+    }
+  };
+
+  // ---- operand geometry -----------------------------------------------------------------------------------------------------
+  const int fi = lane & 15, fg = lane >> 4;
+  constexpr int GPT = TWO ? 2 : 4 / G::TPP;                    // k-groups (8 channels) per tap (TWO: per source)
+  const int jl = fg / GPT;                                     // which tap of the k-step this lane's k-group belongs to (TWO: which source)
+  const int cgl = fg % GPT;                                    // which 8-channel group of the pixel
+  int a_base[MT];                                              // half offset of (tile row, pixel fi, tap 0) in a patch image
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int prow = wave * MT + mi;
+    if (TWO) a_base[mi] = (jl ? G::PP * 16 : 0) + (prow * G::PW + fi) * 16 + 8 * cgl;      // here jl = source, one tap per step
+    else a_base[mi] = (prow * G::PW + fi) * CT + 8 * cgl;
+  }
+  int b_rd[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int row = ni * 16 + fi;
+    b_rd[ni] = row * 32 + 8 * (fg ^ pswz(row));
+  }
+  const float inv_s = a.hdr[1];
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) load_patch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();                                           // every wave is done with the previous tile's patch (and the filter has landed)
+    store_patch();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) load_patch(next);                     // lands under this tile's MFMAs
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < G::NS; ++s) {
+      // tap offset of this lane's k-group: tap = s * TPP + jl (clamped into the filter: the packed filter is zero beyond it)
+      int toff = 0;
+      if (TWO) {
+        toff = ((s / KK) * G::PW + (s % KK)) * 16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < G::TPP; ++j) {
+          const int t = s * G::TPP + j < G::NTAPS ? s * G::TPP + j : 0;
+          const int o = ((t / KK) * G::PW + (t % KK)) * CT;
+          toff = (jl == j) ? o : toff;
+        }
+      }
+      f16x8 wh[NT], wl[NT], ws[NT], ph[MT], pl[MT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        wh[ni] = *reinterpret_cast<const f16x8*>(filt_h + s * G::COUT * 32 + b_rd[ni]);
+        wl[ni] = *reinterpret_cast<const f16x8*>(filt_l + s * G::COUT * 32 + b_rd[ni]);
+        ws[ni] = wh[ni] * (_Float16)(1.0f / 2048.0f);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        int ad = a_base[mi] + toff;
+        if (!TWO && CT == 32) {                                // undo the swizzle of the 64-byte pixel
+          const int pix = ad >> 5;
+          ad = (pix << 5) + 8 * (cgl ^ pswz(pix));
+        }
+        ph[mi] = *reinterpret_cast<const f16x8*>(patch_h + ad);
+        pl[mi] = *reinterpret_cast<const f16x8*>(patch_l + ad);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ph[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[ni], pl[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ph[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane (fi, fg) holds couts 4fg..4fg+3 of pixel (row wave*4 + mi, column fi) per 16-cout tile ----------------
+    int pm = tile;
+    const int tx = pm % a.tiles_x;
+    pm /= a.tiles_x;
+    const int ty = pm % a.tiles_y;
+    const int img = pm / a.tiles_y;
+    const int oh0 = ty * 16, ow0 = tx * 16;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int oh = oh0 + wave * MT + mi, ow = ow0 + fi;
+      if (oh >= a.H || ow >= a.W) continue;
+      const size_t pix = ((size_t)img * a.H + oh) * a.W + ow;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        const int co = ni * 16 + 4 * fg;
+        f32x4 v = acc[mi][ni] * inv_s;
+        // y = act2(affine(act1(acc + bias)) + residual)
+        if (a.cout_valid == G::COUT) {
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
+          if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + co) + *reinterpret_cast<const f32x4*>(a.shift + co);
+          if (a.res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += a.res[pix * a.res_cs + co + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
+          // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
+          *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.cout_valid) {
+              float t = shdr::act_apply(v[e] + (a.bias ? a.bias[co + e] : 0.f), a.act1);
+              if (a.scale) t = t * a.scale[co + e] + a.shift[co + e];
+              if (a.res) t += a.res[pix * a.res_cs + co + e];
+              a.y[pix * a.cout_valid + co + e] = shdr::act_apply(t, a.act2);
+            }
+        }
+      }
+    }
+  }
+#undef filt_h
+#undef filt_l
+#undef patch_h
+#undef patch_l
+}
+
+// max |w| -> hdr[0] (bits)
+__global__ __launch_bounds__(256) void x3n_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+// packed[image][step][co][k]: k = (tap, channel) in natural order, CT channels per tap (the source's C1 [+ C2] real ones, zero beyond),
+// zero beyond the last tap and beyond the real couts; w * x2-scale * 2^S split into wh, wl
+__global__ __launch_bounds__(256) void x3n_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int ntaps,
+                                                       int CT, int C1, int Creal, int cout_real, int Cout_w, int COUT, int NS, float x2_scale) {
+  const float mx = fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[0]) * fmaxf(1.0f, fabsf(x2_scale)), 1e-30f);
+  int ex;
+  frexpf(mx, &ex);
+  int S = 14 - ex;
+  S = S < -100 ? -100 : (S > 100 ? 100 : S);
+  const float s = ldexpf(1.0f, S);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
+  const long total = (long)NS * COUT * 32;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int kk = (int)(e & 31), co = (int)((e >> 5) % COUT), st = (int)(e / (32L * COUT));
+    const int k = st * 32 + kk;
+    const int tap = k / CT, ch = k - tap * CT;
+    float v = 0.0f;
+    if (tap < ntaps && ch < Creal && co < cout_real) {
+      v = w[((size_t)tap * Creal + ch) * Cout_w + co] * s;
+      if (ch >= C1) v *= x2_scale;
+    }
+    const _Float16 h = (_Float16)v;
+    out[e] = h;
+    out[total + e] = (_Float16)(v - (float)h);
+  }
+}
+
+template <int KK, int CT, int NT, bool TWO>
+int launch_x3n(X3nArgs& a, hipStream_t st) {
+  using G = NG<KK, CT, NT, TWO>;
+  constexpr int lds = G::LDS_BYTES;
+  if constexpr (lds > 160 * 1024) {
+    return shdr::fail(SHDR_E_SHAPE, "conv2d_x3n: filter + patch (%d bytes) do not fit the LDS", lds);
+  } else {
+    const int dev_slot = shdr::device_slot();
+    static bool attr_done[shdr::kMaxDevices] = {};
+    static int occ[shdr::kMaxDevices] = {};
+    if (!attr_done[dev_slot]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      int nb = 0;
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO>), 256, lds);
+      occ[dev_slot] = (e != hipSuccess || nb < 1) ? 1 : (nb > 4 ? 4 : nb);
+      attr_done[dev_slot] = true;
+    }
+    long grid = 256L * occ[dev_slot];
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL((conv_x3n_kernel<KK, CT, NT, TWO>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return shdr::check_launch("conv_x3n_kernel");
+  }
+}
+
+inline int ct_of(const shdr_conv2d_desc* d) { return d->C2 > 0 ? 32 : (d->C1 <= 8 ? 8 : (d->C1 <= 16 ? 16 : 32)); }
+
+template <int KK, int NT>
+int dispatch_ct(X3nArgs& a, const shdr_conv2d_desc* d, hipStream_t st) {
+  if (d->C2 > 0) return launch_x3n<KK, 32, NT, true>(a, st);
+  const int ct = ct_of(d);
+  if (ct == 8) return launch_x3n<KK, 8, NT, false>(a, st);
+  if (ct == 16) return launch_x3n<KK, 16, NT, false>(a, st);
+  return launch_x3n<KK, 32, NT, false>(a, st);
+}
+
+}  // namespace
+
+// 1 if the narrow split-operand kernel takes the layer
+extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
+  if (!d || d->stride != 1 || d->KH != d->KW || !(d->KH == 3 || d->KH == 5 || d->KH == 7)) return 0;
+  if (d->pad_t != (d->KH - 1) / 2 || d->pad_l != (d->KW - 1) / 2 || d->Ho != d->H || d->Wo != d->W) return 0;
+  if (!(d->Cout == 16 || d->Cout == 32) || d->w_batch_stride != 0 || d->y_pix_stride > 1 || d->prologue != SHDR_PROLOGUE_NONE) return 0;
+  const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  if (cv > d->Cout || (d->y_cstride != 0 && d->y_cstride != cv)) return 0;
+  const bool one = d->C2 == 0 && d->C1 % 4 == 0 && d->C1 >= 4 && d->C1 <= 32, two = d->C1 == 16 && d->C2 == 16;
+  if (!(one || two) || getenv("SHDR_NO_X3") || getenv("SHDR_NO_X3N")) return 0;
+  if ((long)d->N * d->H * d->W * 32 >= (1L << 31)) return 0;
+  const int ct = ct_of(d);
+  const long filt = 2L * ((d->KH * d->KW * ct + 31) / 32) * d->Cout * 64;
+  const long patch = 2L * (16 + d->KH - 1) * (16 + d->KW - 1) * ct * 2;
+  if (filt + patch > 150 * 1024) return 0;
+  long min_tiles = 256;                                     // persistent blocks: at least one tile per CU
+  if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_tiles = atol(e);
+  return (long)d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16) >= min_tiles ? 1 : 0;
+}
+
+extern "C" int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d) {
+  if (!d || d->KH <= 0 || !(d->Cout == 16 || d->Cout == 32)) return -1;
+  const int ct = ct_of(d);
+  const int64_t ns = (d->KH * d->KW * ct + 31) / 32;
+  return XN_HEADER_FLOATS + ns * d->Cout * 32;               // header + two fp16 images, in floats
+}
+
+// w: HWIO [KH][KW][C1 + C2][cout_w] with cout_w = the filter tensor's channel count (>= cout_valid; the desc's Cout may be its padding)
+extern "C" int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream) {
+  SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "conv2d_x3n_prepare_filter: null pointer");
+  SHDR_REQUIRE(shdr::aligned16(prepared), SHDR_E_ALIGN, "conv2d_x3n_prepare_filter: prepared must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ct = ct_of(d), Creal = d->C1 + d->C2, ntaps = d->KH * d->KW, ns = (ntaps * ct + 31) / 32;
+  const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  if (hipMemsetAsync(prepared, 0, XN_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3n_prepare_filter: memset");
+  const long nw = (long)ntaps * Creal * d->Cout;             // the filter tensor handed over has the desc's (padded) Cout columns
+  hipLaunchKernelGGL(x3n_absmax_kernel, dim3(shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64), dim3(256), 0, st, w, nw,
+                     reinterpret_cast<unsigned*>(prepared));
+  hipLaunchKernelGGL(x3n_pack_kernel, dim3(shdr::stream_grid((long)ns * d->Cout * 32)), dim3(256), 0, st, w, prepared,
+                     reinterpret_cast<_Float16*>(prepared + XN_HEADER_FLOATS), ntaps, ct, d->C1, Creal, cv, d->Cout, d->Cout, ns,
+                     d->C2 > 0 ? d->x2_scale : 1.0f);
+  return shdr::check_launch("conv2d_x3n_prepare_filter");
+}
+
+extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                       const float* scale, const float* shift, const float* residual, float* y, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && y, SHDR_E_NULL, "conv2d_x3n: null desc/x1/filter/y");
+  SHDR_REQUIRE(shdr_conv2d_x3n_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3n: layer shape not taken by this kernel");
+  SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3n: x2 must be given iff C2 > 0");
+  SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3n: scale and shift come together");
+  SHDR_REQUIRE(!residual || d->res_cstride >= (d->cout_valid > 0 ? d->cout_valid : d->Cout), SHDR_E_SHAPE, "conv2d_x3n: res_cstride");
+  SHDR_REQUIRE(shdr::aligned16(x1) && (!x2 || shdr::aligned16(x2)) && shdr::aligned16(prepared) && shdr::aligned16(y) && (!bias || shdr::aligned16(bias)),
+               SHDR_E_ALIGN, "conv2d_x3n: tensors must be 16-byte aligned");
+  X3nArgs a{};
+  a.x1 = x1; a.x2 = x2;
+  a.hdr = prepared;
+  a.wp = reinterpret_cast<const _Float16*>(prepared + XN_HEADER_FLOATS);
+  a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1;
+  a.tiles_x = (d->W + 15) / 16;
+  a.tiles_y = (d->H + 15) / 16;
+  a.ntiles = a.N * a.tiles_x * a.tiles_y;
+  a.act1 = d->act1; a.act2 = d->act2;
+  a.cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+  a.res_cs = d->res_cstride;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->Cout == 16) {
+    if (d->KH == 3) return dispatch_ct<3, 1>(a, d, st);
+    if (d->KH == 5) return dispatch_ct<5, 1>(a, d, st);
+    return dispatch_ct<7, 1>(a, d, st);
+  }
+  if (d->KH == 3) return dispatch_ct<3, 2>(a, d, st);
+  if (d->KH == 5) return dispatch_ct<5, 2>(a, d, st);
+  return dispatch_ct<7, 2>(a, d, st);
+}

@@ -424,6 +424,39 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     assert torch.equal(K.conv2d(dev(x), dev(wt), None, act1=K.ACT_RELU), y)
 
 
+X3N_CASES = [  # name, n, h, w, c1, c2, cout (filter width), cout_valid, k, act1, residual
+    ("deq_conv1_7x7_4_16", 1, 40, 52, 4, 0, 16, 16, 7, 2, False), ("deq_conv2_7x7_16_16", 2, 33, 47, 16, 0, 16, 16, 7, 2, False),
+    ("deq_d2_5x5_16_32", 1, 24, 40, 16, 0, 32, 32, 5, 2, False), ("deq_u1_3x3_32_16", 1, 50, 34, 32, 0, 16, 16, 3, 2, False),
+    ("deq_u1_concat_16_16_16", 2, 21, 35, 16, 16, 16, 16, 3, 2, False), ("deq_out_3x3_16_3_tanh_residual", 1, 36, 36, 16, 0, 16, 3, 3, 3, True),
+    ("ref_conv1_7x7_12_16", 1, 20, 28, 12, 0, 16, 16, 7, 2, False), ("d3_3x3_32_32", 1, 18, 18, 32, 0, 32, 32, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", X3N_CASES, ids=[c[0] for c in X3N_CASES])
+def test_conv2d_x3n_narrow_layers(shdr, case, monkeypatch):
+    """SHDR_PLAN_X3N (csrc/conv_x3n.hip): the narrow full-resolution layers of the Dequantization- / Refinement-Net on the split-operand
+    arithmetic (whole filter in LDS, 32 / CT taps per MFMA): zero-padded input channels (3 -> 4, 9 -> 12), two sources, 3-channel head
+    with tanh + residual, ragged tiles; vs the float64 oracle at the exact-fp32 kernels' bar and next to the exact kernel's error"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    name, n, h, w, c1, c2, cout, cv, k, act, with_res = case
+    rng = np.random.default_rng(len(name) + h)
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, c1)))
+    x2 = f32(rng.normal(size=(n, h, w, c2))) if c2 else None
+    wt = f32(rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2)))
+    wt[..., cv:] = 0.0
+    b = f32(rng.normal(size=cv))
+    res = f32(rng.normal(size=(n, h, w, cv))) if with_res else None
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, has_residual=with_res, cout_valid=cv) == "x3n"
+    ref = oracle_conv(x, wt[..., :cv], b, x2=x2, act1=act, residual=res)
+    kw = dict(x2=None if x2 is None else dev(x2), act1=act, residual=None if res is None else dev(res), cout_valid=cv)
+    y = K.conv2d(dev(x), dev(wt), dev(b), **kw)
+    err = rel_err(host(y), ref)
+    monkeypatch.setattr(K, "EXACT_FP32", True)
+    err_exact = rel_err(host(K.conv2d(dev(x), dev(wt), dev(b), **kw)), ref)
+    assert tuple(y.shape) == ref.shape and err <= TOL and err <= 4 * err_exact + 2e-7, (err, err_exact)
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128)])
 def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
     """1x1 layers with K >= 256 on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet

@@ -19,6 +19,9 @@ SHAPES = [  # n, h, w, c1, c2, cout
     (16, 512, 512, 96, 0, 64, 7, 2),          # the Linearization-Net stem: four phase launches
     (16, 32, 32, 512, 512, 512, 1, 1), (16, 64, 64, 512, 512, 512, 1, 1), (16, 128, 128, 256, 256, 256, 1, 1),      # hal skip layers (1x1 on a concat)
     (16, 256, 256, 128, 128, 128, 1, 1), (16, 512, 512, 64, 64, 64, 1, 1), (16, 128, 128, 256, 0, 64, 1, 1), (16, 64, 64, 512, 0, 128, 1, 1),
+    # the narrow full-resolution layers of the U-Nets (plan "x3n")
+    (16, 512, 512, 4, 0, 16, 7, 1), (16, 512, 512, 16, 0, 16, 7, 1), (16, 256, 256, 16, 0, 32, 5, 1), (16, 256, 256, 32, 0, 32, 5, 1),
+    (16, 512, 512, 32, 0, 16, 3, 1), (16, 512, 512, 16, 16, 16, 3, 1), (16, 512, 512, 16, 0, 16, 3, 1),
 ]
 
 
