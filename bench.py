@@ -339,7 +339,7 @@ def main():
                     wino = K.conv2d_plan(tuple(x.shape), tuple(w.shape), c2=0 if x2 is None else x2.shape[3], stride=stride,
                                          x2_scale=kw.get("x2_scale", 1.0), has_residual=kw.get("residual") is not None,
                                          cout_valid=kw.get("cout_valid"))
-                    if wino not in ("x3", "fused", "planes"):
+                    if wino not in ("x3", "x3n", "fused", "planes"):
                         wino = None
                 e0.record()
                 depth[0] += 1
@@ -350,7 +350,7 @@ def main():
                 e1.record()
                 label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
                          "winograd_fused_kernel" if wino == "fused" else "conv_x3_kernel" if wino == "x3" else
-                         conv_variant(w, x, x2, kw.get("algo", 0), stride))
+                         "conv_x3n_kernel" if wino == "x3n" else conv_variant(w, x, x2, kw.get("algo", 0), stride))
                 records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
                                 "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
                                                             0 if x2 is None else x2.shape[3], w.shape[3], w.shape[0], stride),
@@ -426,7 +426,7 @@ def main():
                     a = agg.setdefault(var, [0.0, 0.0, 0])
                     # per KERNEL the MFMA FLOPs it executes: the fused Winograd kernel runs 16 / 36 of the layer's direct-form FLOPs,
                     # the split-operand kernel three fp16 MFMA products per fp32 product
-                    a[0] += fl / 2.25 if var == "winograd_fused_kernel" else 3.0 * fl if var == "conv_x3_kernel" else fl
+                    a[0] += fl / 2.25 if var == "winograd_fused_kernel" else 3.0 * fl if var in ("conv_x3_kernel", "conv_x3n_kernel") else fl
                     a[1] += sec; a[2] += 1
             reps = 1             # `calls` holds one pass
             dom = max(agg, key=lambda k: agg[k][1])
@@ -449,19 +449,20 @@ def main():
                 traffic = int(sum(b * n for b, n in hits) / sum(n for _, n in hits)) if hits else None
             except (OSError, KeyError, ValueError):
                 pass
-            peak_of = lambda k: F16_MFMA_PEAK_TFLOPS if k == "conv_x3_kernel" else F32_MFMA_PEAK_TFLOPS      # noqa: E731
-            to_alg = {"winograd_fused_kernel": 2.25, "conv_x3_kernel": 1.0 / 3.0}.get(dom, 1.0)
+            X3K = ("conv_x3_kernel", "conv_x3n_kernel")
+            peak_of = lambda k: F16_MFMA_PEAK_TFLOPS if k in X3K else F32_MFMA_PEAK_TFLOPS      # noqa: E731
+            to_alg = {"winograd_fused_kernel": 2.25, "conv_x3_kernel": 1.0 / 3.0, "conv_x3n_kernel": 1.0 / 3.0}.get(dom, 1.0)
             # time the matrix pipes need for one step at their peaks (fp32-MFMA kernels against 157.3, the fp16 split kernel against 2500)
             floor_ms = sum(a[0] / (peak_of(k) * 1e12) for k, a in agg.items()) * 1e3
             result["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak_of(dom),
                 "unit": "TFLOP/s", "frac": round(achieved / peak_of(dom), 4),
-                "mfma_dtype": "f16 (v_mfma_f32_16x16x32_f16, three products per fp32 product)" if dom == "conv_x3_kernel" else "f32 (v_mfma_f32_16x16x4_f32)",
+                "mfma_dtype": "f16 (v_mfma_f32_16x16x32_f16, three products per fp32 product)" if dom in X3K else "f32 (v_mfma_f32_16x16x4_f32)",
                 # SURVEY.md section 8(d) convention: the reference layers' direct-form fp32 FLOPs against the fp32-MFMA peak, no discount
                 # for what Winograd saves and no surcharge for the three fp16 products of the split kernel
                 "frac_algorithmic": round(achieved * to_alg / F32_MFMA_PEAK_TFLOPS, 4),
-                "whole_step": {"executed_gflop_f32_mfma": round(sum(a[0] for k, a in agg.items() if k != "conv_x3_kernel") / 1e9, 1),
-                               "executed_gflop_f16_mfma": round(sum(a[0] for k, a in agg.items() if k == "conv_x3_kernel") / 1e9, 1),
+                "whole_step": {"executed_gflop_f32_mfma": round(sum(a[0] for k, a in agg.items() if k not in X3K) / 1e9, 1),
+                               "executed_gflop_f16_mfma": round(sum(a[0] for k, a in agg.items() if k in X3K) / 1e9, 1),
                                "mfma_floor_ms": round(floor_ms, 3),
                                "frac_executed": round(floor_ms / ms_per_step, 4),
                                "frac_algorithmic": round(conv_total_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),

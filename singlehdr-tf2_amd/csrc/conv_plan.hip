@@ -169,7 +169,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
 // 128 -> 64 2.70 -> 2.03 ms, 256 -> 128 2.13 -> 1.88, 512 -> 256 1.86 -> 1.79, 512 -> 512 0.91 -> 0.96: fused up to 256 couts
 inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) {
   if (d->C2 != 0) return false;
-  if (plan == SHDR_PLAN_X3) return d->Cout <= 256 || getenv("SHDR_X3_UP_ALWAYS") != nullptr;
+  if (plan == SHDR_PLAN_X3) return d->KH == 3 && d->stride == 1 && (d->Cout <= 256 || getenv("SHDR_X3_UP_ALWAYS") != nullptr);
   return plan == SHDR_PLAN_WINOGRAD_FUSED;
 }
 // bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)

@@ -478,8 +478,7 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad_t == 1 && d->pad_l == 1;
     // 1 x 1 layers (the skip layers of hallucination_net.py:93-107 on tf.concat of two sources, the bottleneck convs of the ResNet
     // blocks): one tap per chunk, so the patch split is not amortised over nine taps -- still 2-3x the fp32-MFMA kernel from K = 256 on
-    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && d->prologue == SHDR_PROLOGUE_NONE &&
-                    getenv("SHDR_NO_X3_1X1") == nullptr;
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && getenv("SHDR_NO_X3_1X1") == nullptr;
     if (!(k3 || k1) || d->Ho != d->H || d->Wo != d->W) return 0;
   } else {
     // the 7 x 7 / stride-2 stem with TF SAME padding (one source, no prologue)

@@ -339,7 +339,9 @@ int dispatch_ct(X3nArgs& a, const shdr_conv2d_desc* d, hipStream_t st) {
 extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
   if (!d || d->stride != 1 || d->KH != d->KW || !(d->KH == 3 || d->KH == 5 || d->KH == 7)) return 0;
   if (d->pad_t != (d->KH - 1) / 2 || d->pad_l != (d->KW - 1) / 2 || d->Ho != d->H || d->Wo != d->W) return 0;
-  if (!(d->Cout == 16 || d->Cout == 32) || d->w_batch_stride != 0 || d->y_pix_stride > 1 || d->prologue != SHDR_PROLOGUE_NONE) return 0;
+  // (desc.prologue plays no part: the plan of a layer must not depend on it -- shdr_conv2d_fwd_prepared_f32 materialises a prologue this
+  //  kernel does not fuse and re-enters with the same prepared filter)
+  if (!(d->Cout == 16 || d->Cout == 32) || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv > d->Cout || (d->y_cstride != 0 && d->y_cstride != cv)) return 0;
   const bool one = d->C2 == 0 && d->C1 % 4 == 0 && d->C1 >= 4 && d->C1 <= 32, two = d->C1 == 16 && d->C2 == 16;
