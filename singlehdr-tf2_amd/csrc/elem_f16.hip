@@ -654,15 +654,57 @@ __device__ __forceinline__ float lin_feature(const float* __restrict__ img, long
   const float d = fabsf(xv - centre);
   return d < 1.0f / (float)B ? 1.0f - d * (float)B : 0.0f;
 }
+// Block roles (no divergence inside a wave): every sixth block writes the two leading octets (image, sobel, first histogram channels:
+// the general per-channel form, 18 neighbour loads per pixel and colour), the others the ten pure-histogram octets -- a thread owns ONE
+// of them for all its pixels, so bin centre, bin count and colour index of its eight channels are computed once, then 3 loads + 8 hat
+// functions + one 16-byte store per pixel (the element-major form decoded the channel per value: 0.92 ms for 4 x 1024^2).  YC = 96.
 __global__ __launch_bounds__(256) void lin_frontend_h_kernel(const float* __restrict__ img, hf* __restrict__ y, int N, int H, int W, int YC) {
   const int O = YC >> 3;
-  const long total = (long)N * H * W * O;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    DECODE8(e, O, W, H, o, w, h, n)
-    V8 r;
+  const long npix = (long)N * H * W;
+  const bool lead = blockIdx.x % 6 == 0;
+  if (!lead) {
+    const int OH = O - 2;                                      // histogram octets 2 .. O-1
+    const long bid = blockIdx.x - blockIdx.x / 6 - 1, nb = gridDim.x - (gridDim.x + 5) / 6;       // index among the histogram blocks
+    const long t0 = bid * 256 + threadIdx.x, nthr = nb * 256;  // nthr is a multiple of OH (launcher)
+    const int o = 2 + (int)(t0 % OH);
+    int cj[8];
+    float centre[8], fB[8], wB[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = lin_feature(img, n, h, w, H, W, 8 * o + j);
-    sth(y + e * 8, r);
+    for (int j = 0; j < 8; ++j) {
+      const int ch = 8 * o + j;
+      int B = 4, r = ch - 9;
+      if (ch >= 45) { B = 16; r = ch - 45; } else if (ch >= 21) { B = 8; r = ch - 21; }
+      const int bin = r / 3 + 1;
+      cj[j] = ch < 93 ? r - 3 * (r / 3) : -1;
+      centre[j] = (float)(2 * bin - 1) / (float)(2 * B);
+      fB[j] = (float)B;
+      wB[j] = 1.0f / (float)B;
+    }
+    for (long p = t0 / OH; p < npix; p += nthr / OH) {
+      const float x3[3] = {img[3 * p], img[3 * p + 1], img[3 * p + 2]};
+      V8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = cj[j] == 1 ? x3[1] : (cj[j] == 2 ? x3[2] : x3[0]);
+        const float d = fabsf(xv - centre[j]);
+        r.v[j] = (cj[j] >= 0 && d < wB[j]) ? 1.0f - d * fB[j] : 0.0f;
+      }
+      sth(y + (p * O + o) * 8, r);
+    }
+  } else {
+    const long bid = blockIdx.x / 6, nb = (gridDim.x + 5) / 6;
+    const long t0 = bid * 256 + threadIdx.x, nthr = nb * 256;
+    const int o = (int)(t0 & 1);
+    for (long p = t0 >> 1; p < npix; p += nthr >> 1) {
+      const int w = (int)(p % W);
+      const long t = p / W;
+      const int h = (int)(t % H);
+      const long n = t / H;
+      V8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = lin_feature(img, n, h, w, H, W, 8 * o + j);
+      sth(y + (p * O + o) * 8, r);
+    }
   }
 }
 // dimg[n,h,w,c] = dF[c] + sum of the sobel transposes + sum_bins dF[hist] * (-+B inside the bin support); gather form, no atomics
@@ -930,8 +972,11 @@ extern "C" int shdr_lin_frontend_fwd_f16(const float* img, void* y, int N, int H
   SHDR_REQUIRE(N > 0 && H >= 2 && W >= 2 && y_channels >= 93 && y_channels % 8 == 0, SHDR_E_SHAPE,
                "lin_frontend_f16: need H, W >= 2 and y_channels >= 93, a multiple of 8");
   SHDR_REQUIRE(shdr::aligned16(y), SHDR_E_ALIGN, "lin_frontend_f16: y must be 16-byte aligned");
-  hipLaunchKernelGGL(lin_frontend_h_kernel, dim3(shdr::stream_grid((long)N * H * W * (y_channels / 8))), dim3(256), 0, S(stream), img, HM_(y),
-                     N, H, W, y_channels);
+  SHDR_REQUIRE(y_channels == 96, SHDR_E_SHAPE, "lin_frontend_f16: built for the 96-channel (93 + 3 zero) layout");
+  // 6 blocks per group: one leading-octet block + five histogram blocks (5 * 256 threads = a multiple of the 10 histogram octets)
+  long groups = ((long)N * H * W * 12 + 6 * 256 - 1) / (6 * 256);
+  groups = groups < 1 ? 1 : (groups > 342 ? 342 : groups);
+  hipLaunchKernelGGL(lin_frontend_h_kernel, dim3((unsigned)(6 * groups)), dim3(256), 0, S(stream), img, HM_(y), N, H, W, y_channels);
   return shdr::check_launch("lin_frontend_f16");
 }
 extern "C" int shdr_lin_frontend_bwd_f16(const float* img, const void* dF, float* dimg, int N, int H, int W, int y_channels, void* stream) {
