@@ -84,3 +84,51 @@ def test_frontend_quad_switch_is_bit_identical(shdr, monkeypatch):
     gots = [K.soft_hist(img, 32), K.soft_hist(img, 12), K.lin_frontend(img, 96)]
     for a, r in zip(gots, refs):
         assert torch.equal(a, r)
+
+
+@pytest.mark.parametrize("var,shape", [
+    ("SHDR_NO_X3", (2, 48, 64, 64, 0, 128, 3, 1)), ("SHDR_NO_X3", (1, 40, 40, 64, 64, 64, 3, 1)), ("SHDR_NO_X3_1X1", (1, 40, 56, 256, 256, 128, 1, 1)),
+    ("SHDR_NO_X3_STRIDE2", (1, 64, 80, 96, 0, 64, 7, 2)), ("SHDR_NO_X3N", (1, 40, 56, 16, 0, 16, 7, 1)), ("SHDR_NO_X3N", (1, 40, 56, 16, 16, 16, 3, 1)),
+    ("SHDR_NO_WINOGRAD", (1, 48, 48, 64, 0, 64, 3, 1))])
+def test_split_operand_switches(shdr, monkeypatch, var, shape):
+    """the split-operand fp16 kernels (plans "x3" / "x3n") against the exact-fp32 kernel the switch falls back to: both fp32-grade"""
+    K = shdr._ops
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, c1, c2, cout, k, s = shape
+    x, x2 = _rand(n, h, w, c1, seed=20), (_rand(n, h, w, c2, seed=21) if c2 else None)
+    wt, b = _rand(k, k, c1 + c2, cout, seed=22, scale=1.0 / (k * (c1 + c2) ** 0.5)), _rand(cout, seed=23)
+    plan = K.conv2d_plan((n, h, w, c1), tuple(wt.shape), c2=c2, stride=s)
+    assert plan in ("x3", "x3n")
+    got = K.conv2d(x, wt, b, stride=s, x2=x2, act1=K.ACT_RELU)
+    monkeypatch.setenv(var, "1")
+    assert K.conv2d_plan((n, h, w, c1), tuple(wt.shape), c2=c2, stride=s) not in ("x3", "x3n")
+    ref = K.conv2d(x, wt, b, stride=s, x2=x2, act1=K.ACT_RELU)
+    assert maxrel(got, ref) <= 5e-6, (var, plan)
+
+
+def test_x3_up_always_switch_is_bit_identical(shdr, monkeypatch):
+    """the bilinear prologue fused into the split kernel at 512 couts (the plan fuses it up to 256) = resize2x + the same kernel"""
+    K = shdr._ops
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    x, wt, b = _rand(1, 12, 20, 64, seed=24), _rand(3, 3, 64, 512, seed=25, scale=0.04), _rand(512, seed=26)
+    ref = K.conv2d_up2(x, wt, b, act1=K.ACT_RELU)
+    monkeypatch.setenv("SHDR_X3_UP_ALWAYS", "1")
+    assert torch.equal(K.conv2d_up2(x, wt, b, act1=K.ACT_RELU), ref)
+
+
+@pytest.mark.parametrize("var", ["SHDR_NO_W3", "SHDR_NO_PATCH"])
+def test_fp16_specialised_conv_switches(shdr, monkeypatch, var):
+    """native-fp16 path: the 3x3 raw-patch kernel / the narrow-layer patch kernel vs the general implicit-GEMM kernel (same products,
+    fp32 accumulation in another order, fp16 output rounding)"""
+    K = shdr._ops
+    monkeypatch.setenv("SHDR_W3_MIN_BLOCKS", "1")
+    if var == "SHDR_NO_W3":
+        x, wt = _rand(2, 32, 48, 64, seed=27).half(), _rand(3, 3, 64, 64, seed=28, scale=0.04)
+    else:
+        x, wt = _rand(2, 32, 48, 16, seed=27).half(), _rand(7, 7, 16, 16, seed=28, scale=0.04)
+    b = _rand(wt.shape[3], seed=29)
+    with K.precision("fp16"):
+        got = K.conv2d(x, wt, b, act1=K.ACT_RELU)
+        monkeypatch.setenv(var, "1")
+        ref = K.conv2d(x, wt, b, act1=K.ACT_RELU)
+    assert got.dtype == torch.float16 and maxrel(got.float(), ref.float()) <= 2e-3
