@@ -123,17 +123,6 @@ class Conv2D(Layer):
             self._padded = (key, pad)
         return self._padded[1]
 
-    def kernel_x2_scaled(self, c1, scale):
-        """Kernel whose input-channel rows [c1:] are multiplied by `scale` (cached per parameter
-        version): conv(concat[x, scale*x2], W) == conv(concat[x, x2], W') -- lets the two-source
-        conv run on the LDS-DMA kernel, which cannot scale data in flight."""
-        key = (self.kernel._version, "x2", c1, float(scale))
-        if self._padded is None or self._padded[0] != key:
-            k = self.kernel.detach().clone()
-            k[:, :, c1:, :] *= scale
-            self._padded = (key, k.contiguous())
-        return self._padded[1]
-
     def call_padded(self, x, cin_pad=None, cout_pad=None, **kw):
         """Run on the MFMA tile with a zero-padded filter; stores only the true output channels."""
         if torch.is_grad_enabled() and self.kernel.requires_grad:

@@ -76,10 +76,7 @@ class skipLayer(Layer):
         self.conv1 = Conv2D(xChannels + skChannels, outChannels, (1, 1), device=device)
 
     def call(self, x, sk, **kw):
-        c1 = x.shape[-1]
-        if c1 % 4 == 0 and sk.shape[-1] % 4 == 0 and not (torch.is_grad_enabled() and self.conv1.kernel.requires_grad):
-            # fold the 1/255 into the sk rows of the filter (cached) -> LDS-DMA conv kernel
-            return K.conv2d(x, self.conv1.kernel_x2_scaled(c1, 1.0 / 255), self.conv1.bias, x2=sk, **kw)
+        # the 1/255 of the skip source is folded into the filter rows by the library's filter preparation (cached per parameter version)
         return self.conv1(x, x2=sk, x2_scale=1.0 / 255, **kw)
 
 
