@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void subfilter_kernel(const float* __restrict_
 
 struct DgradGeom {
   int c_begin, c_count, cout_real, CZ, CC;      // CZ: dz channels the conv reads (multiple of 4), CC: conv output channels (padded to 16 when narrow)
-  bool pad_dz, wino, x3;
+  bool pad_dz, wino, x3, x3n;
   size_t off_wt, off_u, off_dz, off_sub, total;
 };
 
@@ -112,11 +112,20 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
     t.Ho = d->H; t.Wo = d->W; t.cout_valid = g.CC;
     g.x3 = shdr_conv2d_x3_ok_f32(&t) != 0;
   }
+  // the narrow stride-1 layers of the U-Nets: the split-operand kernel with the whole (transposed) filter in LDS
+  g.x3n = false;
+  shdr_conv2d_desc tn{};
+  if (d->algo == SHDR_ALGO_AUTO && d->stride == 1 && d->KH == d->KW && !g.pad_dz && getenv("SHDR_NO_WINOGRAD") == nullptr) {
+    tn.N = d->N; tn.H = d->Ho; tn.W = d->Wo; tn.C1 = g.CZ; tn.Cout = g.CC; tn.KH = d->KH; tn.KW = d->KW; tn.stride = 1;
+    tn.pad_t = (d->KH - 1) - d->pad_t; tn.pad_l = (d->KW - 1) - d->pad_l; tn.Ho = d->H; tn.Wo = d->W; tn.cout_valid = g.c_count;
+    g.x3n = shdr_conv2d_x3n_ok_f32(&tn) != 0;
+  }
   const size_t filt = (size_t)d->KH * d->KW * g.CZ * g.CC * sizeof(float);
   size_t o = 0;
   g.off_wt = o; o += up256(filt);
   g.off_u = o;
-  if (g.x3) o += up256((size_t)(X3_HEADER_FLOATS_PUB + (int64_t)9 * g.CZ * g.CC) * sizeof(float));
+  if (g.x3n) o += up256((size_t)shdr_conv2d_x3n_filter_elems_f32(&tn) * sizeof(float));
+  else if (g.x3) o += up256((size_t)(X3_HEADER_FLOATS_PUB + (int64_t)9 * g.CZ * g.CC) * sizeof(float));
   else if (g.wino) o += up256((size_t)16 * g.CZ * g.CC * sizeof(float));
   g.off_dz = o; if (g.pad_dz) o += up256((size_t)d->N * d->Ho * d->Wo * g.CZ * sizeof(float));
   g.off_sub = o; if (d->stride == 2 && !(d->KH == 1 && d->KW == 1)) o += up256(filt);
@@ -282,6 +291,14 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
   c.cout_valid = g.c_count; c.algo = d->algo;             // (the reduced-precision operand modes carry over to the gradient convs)
   if (d->stride == 1) {
     c.KH = d->KH; c.KW = d->KW; c.pad_t = (d->KH - 1) - d->pad_t; c.pad_l = (d->KW - 1) - d->pad_l; c.Ho = d->H; c.Wo = d->W;
+    if (g.x3n) {
+      float* u = reinterpret_cast<float*>(ws + g.off_u);
+      c.algo = SHDR_ALGO_AUTO;
+      if (int rc = shdr_conv2d_x3n_prepare_filter_f32(&c, wt, u, stream)) return rc;
+      if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;       // header slot 2, as the wide kernel
+      c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
+      return shdr_conv2d_fwd_x3n_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, nullptr, dx, stream);
+    }
     if (g.x3) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;

@@ -35,6 +35,7 @@ struct X3nArgs {
   const float* res;        // residual [N,H,W,res_cs] (or null)
   float* y;                // [N,H,W,cout_valid]
   int N, H, W, C1, tiles_x, tiles_y, ntiles, act1, act2, cout_valid, res_cs;
+  int rs;                  // range scale: multiply the input by the power of two that brings hdr[2] = max |x| to [2^10, 2^11) (output gradients)
 };
 
 __host__ __device__ inline int pswz(int row) { return (-(row >> 2)) & 3; }
@@ -104,6 +105,18 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       pch[j] = (ok && 4 * c4 < a.C1) ? 4 * c4 : -1;            // channels beyond the source's (3 -> 4, 9 -> 12 padded inputs) are zero
     }
   }
+  float xs = 1.0f, ixs = 1.0f;                                 // rs: input scale 2^T and its inverse (conv_x3.hip, SHDR_PROLOGUE_RANGE_SCALE)
+  if (a.rs) {
+    const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(a.hdr)[2]);
+    if (mx > 0.0f) {
+      int ex;
+      frexpf(mx, &ex);
+      int T = 11 - ex;
+      T = T < -100 ? -100 : (T > 100 ? 100 : T);
+      xs = ldexpf(1.0f, T);
+      ixs = ldexpf(1.0f, -T);
+    }
+  }
   f32x4 pr[G::PJ];
   auto load_patch = [&](int tile) __attribute__((always_inline)) {
     int pm = tile;
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       f16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = pr[j][e];
+        const float v = a.rs ? pr[j][e] * xs : pr[j][e];       // uniform branch
         h[e] = (_Float16)v;
         l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
       }
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
     const int row = ni * 16 + fi;
     b_rd[ni] = row * 32 + 8 * (fg ^ pswz(row));
   }
-  const float inv_s = a.hdr[1];
+  const float inv_s = a.hdr[1] * ixs;
 
   int tile = blockIdx.x;
   if (tile < a.ntiles) load_patch(tile);
@@ -399,6 +412,7 @@ extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x
   a.tiles_y = (d->H + 15) / 16;
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   a.act1 = d->act1; a.act2 = d->act2;
+  a.rs = d->prologue == SHDR_PROLOGUE_RANGE_SCALE;
   a.cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   a.res_cs = d->res_cstride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -457,6 +457,31 @@ def test_conv2d_x3n_narrow_layers(shdr, case, monkeypatch):
     assert tuple(y.shape) == ref.shape and err <= TOL and err <= 4 * err_exact + 2e-7, (err, err_exact)
 
 
+@pytest.mark.parametrize("case", [(2, 33, 47, 16, 0, 16, 7, 0), (1, 24, 40, 16, 0, 32, 5, 0), (1, 21, 35, 16, 16, 16, 3, 0), (1, 21, 35, 16, 16, 16, 3, 1),
+                                  (1, 30, 30, 32, 0, 16, 3, 0)])
+def test_conv2d_x3n_input_gradient(shdr, case, monkeypatch):
+    """input gradient of the narrow layers through shdr_conv2d_dgrad_f32 on the split-operand kernel (transposed filter in LDS, output
+    gradients range-scaled in the kernel): tiny, heavy-tailed dz against float64 autograd, L2-relative"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, c1, c2, cout, k, which = case
+    K = shdr._ops
+    g = torch.Generator().manual_seed(sum(case))
+    wt = torch.randn((k, k, c1 + c2, cout), generator=g) / (k * (c1 + c2) ** 0.5)
+    dz = (torch.randn((n, h, w, cout), generator=g) * torch.exp(2.0 * torch.randn((n, h, w, cout), generator=g)) * 1e-6)
+    x = torch.zeros((n, c1 + c2, h, w), dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, wt.double().permute(3, 2, 0, 1), padding=k // 2)
+    y.backward(dz.double().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)[..., (c1 if which else 0):(c1 + c2 if which else c1)]
+    cx = c2 if which else c1
+    dx = K.conv2d_dgrad(dz.cuda(), wt.cuda(), (n, h, w, cx), c1, c2, which)
+    err = float((dx.double().cpu() - ref).norm() / ref.norm())
+    monkeypatch.setattr(K, "EXACT_FP32", True)
+    dxe = K.conv2d_dgrad(dz.cuda(), wt.cuda(), (n, h, w, cx), c1, c2, which)
+    err_exact = float((dxe.double().cpu() - ref).norm() / ref.norm())
+    assert err <= 2e-6 and err <= 4 * err_exact + 2e-7, (err, err_exact)
+    assert not torch.equal(dx, dxe)                     # ... and it did take another kernel
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128)])
 def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
     """1x1 layers with K >= 256 on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet
