@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--no-refinement", action="store_true", help="skip the extra inference leg with the Refinement-Net")
     ap.add_argument("--layers", action="store_true", help="print a per-conv-launch table to stderr")
     ap.add_argument("--streams", type=int, default=2, help="inference: batch slices run on this many HIP streams")
+    ap.add_argument("--exact-fp32", action="store_true", help="every layer on the exact-fp32 kernels (no split-operand fp16 kernels)")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one HIP graph (small-batch latency)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed joint-training steps (0 = skip that leg)")
     ap.add_argument("--train-batch", type=int, default=32)
@@ -203,6 +204,7 @@ def main():
 
     pkg = importlib.import_module("singlehdr-tf2_amd")
     K = pkg._ops
+    K.EXACT_FP32 = bool(args.exact_fp32)
     torch.manual_seed(1234)
     gen = torch.Generator().manual_seed(4321)
     deq = pkg.dequantization_net.model()
@@ -246,14 +248,33 @@ def main():
         "value": round(value, 3), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dtype_note": "fp32 tensors, fp32 results; the wide 3x3 layers compute every fp32 product as three fp16 MFMA products of split operands "
-                      "with fp32 accumulation (csrc/conv_x3.hip: 3 * 2^-22 per product, held to the exact-fp32 kernels' 1e-5 bar against the "
-                      "float64 oracle); all other layers exact fp32 (fp32 MFMA / FMA)",
+        "dtype_note": "fp32 tensors, fp32 results; the wide 3x3 layers, the 7x7/2 stem, the 1x1 layers with K >= 256 (csrc/conv_x3.hip) and the "
+                      "narrow U-Net layers (csrc/conv_x3n.hip) compute every fp32 product as three fp16 MFMA products of split operands with "
+                      "fp32 accumulation (3 * 2^-22 per product, held to the exact-fp32 kernels' 1e-5 bar against the float64 oracle); all "
+                      "other layers exact fp32 (fp32 MFMA / FMA); --exact-fp32 runs every layer on the exact kernels",
         "config": {"workload": "BASELINE configs[2]: full deq+lin+hal inference, batch=%d x %dx%d per GPU, "
-                               "fp32 (exact-fp32 MFMA), histogram B=4/8/16" % (args.batch, args.size, args.size),
+                               "fp32 tensors and results, histogram B=4/8/16" % (args.batch, args.size, args.size),
                    "per_gpu_batch": args.batch, "hip_streams_per_gpu": args.streams,
                    "parallelism": "batch-sharded x%d, no collective" % n_gpus},
     }
+    if rank == 0 and n_gpus == 1 and not args.exact_fp32:
+        # the same leg with every layer on the exact-fp32 kernels (fp32 MFMA / FMA products only), and how far the two results are apart
+        K.EXACT_FP32 = True
+        try:
+            for _ in range(2):
+                out_x = run(ldr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nx = max(3, args.steps // 4)
+            for _ in range(nx):
+                out_x = run(ldr)
+            torch.cuda.synchronize()
+            xdt = (time.perf_counter() - t0) / nx
+            result["exact_fp32_kernels_only"] = {"ms_per_step": round(xdt * 1e3, 3), "images_per_s": round(args.batch / xdt, 3),
+                                                 "max_abs_diff_over_max": float((out - out_x).abs().max() / out_x.abs().max())}
+            del out_x
+        finally:
+            K.EXACT_FP32 = False
 
     # ---- BASELINE configs[1]: Dequantization-Net only, batch 8 x 512 x 512 (informational; the headline stays configs[2]) ----
     if not args.no_refinement:
