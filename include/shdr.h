@@ -261,7 +261,9 @@ int shdr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stre
 /* input gradients of the pooling / resize ops; N,H,W,C describe the op's INPUT x. */
 int shdr_avgpool2_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 int shdr_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
-int shdr_maxpool3s2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* y = the forward's pooled output (an element takes a window's gradient only where it equals y and no
+ * earlier element of the window does). */
+int shdr_maxpool3s2_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 int shdr_gap_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream);
 /* dx[n,2i,2j,:] = dy[n,i,j,:], zero elsewhere (input gradient of a 1x1 stride-2 conv). */
@@ -496,7 +498,7 @@ int shdr_avgpool2_bwd_f16(const void* dy, void* dx, int N, int H, int W, int C, 
 int shdr_maxpool2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int shdr_maxpool2_bwd_f16(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int shdr_maxpool3s2_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
-int shdr_maxpool3s2_bwd_f16(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int shdr_maxpool3s2_bwd_f16(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int shdr_resize2x_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int shdr_resize2x_bwd_f16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int shdr_upsample_zero2_f16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);

@@ -296,8 +296,12 @@ AvgPool2Fn = _simple("AvgPool2Fn", lambda x: (K.avgpool2(x), (), tuple(x.shape))
                      lambda s, m, dy: K.avgpool2_bwd(dy, m))
 MaxPool2Fn = _simple("MaxPool2Fn", lambda x: (K.maxpool2(x), (x,), None),
                      lambda s, m, dy: K.maxpool2_bwd(s[0], dy))
-MaxPool3s2Fn = _simple("MaxPool3s2Fn", lambda x: (K.maxpool3s2(x), (x,), None),
-                       lambda s, m, dy: K.maxpool3s2_bwd(s[0], dy))
+def _maxpool3s2_fwd(x):
+    y = K.maxpool3s2(x)
+    return y, (x, y), None
+
+
+MaxPool3s2Fn = _simple("MaxPool3s2Fn", _maxpool3s2_fwd, lambda s, m, dy: K.maxpool3s2_bwd(s[0], s[1], dy))
 Resize2xFn = _simple("Resize2xFn", lambda x: (K.resize2x(x), (), tuple(x.shape)),
                      lambda s, m, dy: K.resize2x_bwd(dy, m))
 GapFn = _simple("GapFn", lambda x: (K.global_avg_pool(x), (), (tuple(x.shape), x.dtype)),

@@ -101,7 +101,7 @@ SIGNATURES = {
     "shdr_add_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     "shdr_avgpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_maxpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
-    "shdr_maxpool3s2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_resize2x_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_gap_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "shdr_upsample_zero2_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
@@ -151,7 +151,7 @@ SIGNATURES = {
     "shdr_maxpool2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_maxpool2_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_maxpool3s2_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
-    "shdr_maxpool3s2_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_maxpool3s2_bwd_f16": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_resize2x_fwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_resize2x_bwd_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_upsample_zero2_f16": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),

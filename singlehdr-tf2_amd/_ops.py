@@ -784,8 +784,9 @@ def maxpool2_bwd(x, dy):
     return _bwd_nhwc("shdr_maxpool2_bwd_f32", x.shape, x, dy)
 
 
-def maxpool3s2_bwd(x, dy):
-    return _bwd_nhwc("shdr_maxpool3s2_bwd_f32", x.shape, x, dy)
+def maxpool3s2_bwd(x, y, dy):
+    """`y` is the forward's output maxpool3s2(x)"""
+    return _bwd_nhwc("shdr_maxpool3s2_bwd_f32", x.shape, x, y, dy)
 
 
 def resize2x_bwd(dy, x_shape):

@@ -199,10 +199,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 }
 
 // MaxPool 3x3/2 SAME (overlapping windows): one thread per input quad gathers from every window
-// that contains it and whose first maximum it is.
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             float* __restrict__ dx, int N, int H, int W, int C,
-                                                             int Ho, int Wo, int pt, int pl) {
+// that contains it and whose first maximum it is.  With the pooled output at hand an element is a
+// candidate only where it equals the window's maximum (one load per window), and only the elements
+// BEFORE it in the window's scan order can still take the gradient from it (the tie rule).
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, float* __restrict__ dx, int N, int H,
+                                                             int W, int C, int Ho, int Wo, int pt, int pl) {
   const int Q = C >> 2;
   const long total = (long)N * H * W * Q;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -214,23 +216,20 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
       for (int ow = max(0, (w + pl - 1) / 2); ow <= min(Wo - 1, (w + pl) / 2); ++ow) {
         const int h0 = 2 * oh - pt, w0 = 2 * ow - pl;
         if (h < h0 || h > h0 + 2 || w < w0 || w > w0 + 2) continue;
-        const float4 g4 = ld4(dy + (((n * Ho + oh) * Wo + ow) * (long)C + 4 * q));
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-        bool win[4] = {true, true, true, true};
-        for (int i = 0; i < 3; ++i) {
-          const int ih = h0 + i;
-          if ((unsigned)ih >= (unsigned)H) continue;
-          for (int j = 0; j < 3; ++j) {
-            const int iw = w0 + j;
-            if ((unsigned)iw >= (unsigned)W) continue;
+        const long widx = ((n * Ho + oh) * Wo + ow) * (long)C + 4 * q;
+        const float4 m4 = ld4(y + widx);
+        bool win[4] = {mine[0] == m4.x, mine[1] == m4.y, mine[2] == m4.z, mine[3] == m4.w};
+        if (!(win[0] | win[1] | win[2] | win[3])) continue;
+        for (int ih = max(h0, 0); ih <= h; ++ih) {
+          const int wend = (ih == h) ? w : min(w0 + 3, W);
+          for (int iw = max(w0, 0); iw < wend; ++iw) {
             const float4 o4 = ld4(x + (((n * H + ih) * W + iw) * (long)C + 4 * q));
-            const float o[4] = {o4.x, o4.y, o4.z, o4.w};
-            const bool before = (ih < h) || (ih == h && iw < w);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (o[c] > mine[c] || (before && o[c] == mine[c])) win[c] = false;
+            win[0] &= o4.x != mine[0]; win[1] &= o4.y != mine[1]; win[2] &= o4.z != mine[2]; win[3] &= o4.w != mine[3];
           }
         }
+        if (!(win[0] | win[1] | win[2] | win[3])) continue;
+        const float4 g4 = ld4(dy + widx);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (win[c]) acc[c] += g[c];
@@ -877,14 +876,16 @@ extern "C" int shdr_maxpool2_bwd_f32(const float* x, const float* dy, float* dx,
                      S(stream), x, dy, dx, N, H, W, C);
   return shdr::check_launch("maxpool2_bwd");
 }
-extern "C" int shdr_maxpool3s2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int shdr_maxpool3s2_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C,
+                                       void* stream) {
   if (int rc = nhwc4("maxpool3s2_bwd", x, dx, N, H, W, C)) return rc;
   SHDR_REQUIRE(dy && shdr::aligned16(dy), SHDR_E_NULL, "maxpool3s2_bwd: dy null or unaligned");
+  SHDR_REQUIRE(y && shdr::aligned16(y), SHDR_E_NULL, "maxpool3s2_bwd: y (the pooled output) null or unaligned");
   int Ho, Wo, pt, pl;
   shdr_same_pad(H, 3, 2, &Ho, &pt);
   shdr_same_pad(W, 3, 2, &Wo, &pl);
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(shdr::stream_grid((long)N * H * W * (C / 4))), dim3(256), 0, S(stream),
-                     x, dy, dx, N, H, W, C, Ho, Wo, pt, pl);
+                     x, y, dy, dx, N, H, W, C, Ho, Wo, pt, pl);
   return shdr::check_launch("maxpool3s2_bwd");
 }
 extern "C" int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {

@@ -283,8 +283,10 @@ __global__ __launch_bounds__(256) void maxpool3s2_h_kernel(const hf* __restrict_
     sth(y + e * 8, m);
   }
 }
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_h_kernel(const hf* __restrict__ x, const hf* __restrict__ dy, hf* __restrict__ dx,
-                                                               int N, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
+// candidates are the elements equal to the window's maximum `y`; only earlier equals can take the gradient (maxpool3s2_bwd_kernel)
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_h_kernel(const hf* __restrict__ x, const hf* __restrict__ y, const hf* __restrict__ dy,
+                                                               hf* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int pt,
+                                                               int pl) {
   const int O = C >> 3;
   const long total = (long)N * H * W * O;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -295,24 +297,25 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_h_kernel(const hf* __restr
       for (int ow = max(0, (w + pl - 1) / 2); ow <= min(Wo - 1, (w + pl) / 2); ++ow) {
         const int h0 = 2 * oh - pt, w0 = 2 * ow - pl;
         if (h < h0 || h > h0 + 2 || w < w0 || w > w0 + 2) continue;
-        const V8 g = ldh(dy + (((n * Ho + oh) * Wo + ow) * (long)C + 8 * o));
-        bool win[8] = {true, true, true, true, true, true, true, true};
-        for (int i = 0; i < 3; ++i) {
-          const int ih = h0 + i;
-          if ((unsigned)ih >= (unsigned)H) continue;
-          for (int k = 0; k < 3; ++k) {
-            const int iw = w0 + k;
-            if ((unsigned)iw >= (unsigned)W) continue;
-            const V8 t = ldh(x + (((n * H + ih) * W + iw) * (long)C + 8 * o));
-            const bool before = (ih < h) || (ih == h && iw < w);
+        const long widx = ((n * Ho + oh) * Wo + ow) * (long)C + 8 * o;
+        const V8 m = ldh(y + widx);
+        unsigned win = 0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-              if (t.v[c] > mine.v[c] || (before && t.v[c] == mine.v[c])) win[c] = false;
+        for (int c = 0; c < 8; ++c) win |= (unsigned)(mine.v[c] == m.v[c]) << c;
+        if (!win) continue;
+        for (int ih = max(h0, 0); ih <= h; ++ih) {
+          const int wend = (ih == h) ? w : min(w0 + 3, W);
+          for (int iw = max(w0, 0); iw < wend; ++iw) {
+            const V8 t = ldh(x + (((n * H + ih) * W + iw) * (long)C + 8 * o));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) win &= ~((unsigned)(t.v[c] == mine.v[c]) << c);
           }
         }
+        if (!win) continue;
+        const V8 g = ldh(dy + widx);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-          if (win[c]) acc.v[c] += g.v[c];
+          if (win >> c & 1) acc.v[c] += g.v[c];
       }
     }
     sth(dx + e * 8, acc);
@@ -888,14 +891,15 @@ extern "C" int shdr_maxpool3s2_fwd_f16(const void* x, void* y, int N, int H, int
                      W, C, Ho, Wo, pt, pl);
   return shdr::check_launch("maxpool3s2_f16");
 }
-extern "C" int shdr_maxpool3s2_bwd_f16(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int shdr_maxpool3s2_bwd_f16(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
   if (int rc = chk8("maxpool3s2_bwd_f16", x, dx, N, H, W, C)) return rc;
   SHDR_REQUIRE(dy && shdr::aligned16(dy), SHDR_E_NULL, "maxpool3s2_bwd_f16: dy null or unaligned");
+  SHDR_REQUIRE(y && shdr::aligned16(y), SHDR_E_NULL, "maxpool3s2_bwd_f16: y (the pooled output) null or unaligned");
   int Ho, Wo, pt, pl;
   shdr_same_pad(H, 3, 2, &Ho, &pt);
   shdr_same_pad(W, 3, 2, &Wo, &pl);
-  hipLaunchKernelGGL(maxpool3s2_bwd_h_kernel, dim3(shdr::stream_grid((long)N * H * W * (C / 8))), dim3(256), 0, S(stream), H_(x), H_(dy),
-                     HM_(dx), N, H, W, C, Ho, Wo, pt, pl);
+  hipLaunchKernelGGL(maxpool3s2_bwd_h_kernel, dim3(shdr::stream_grid((long)N * H * W * (C / 8))), dim3(256), 0, S(stream), H_(x), H_(y),
+                     H_(dy), HM_(dx), N, H, W, C, Ho, Wo, pt, pl);
   return shdr::check_launch("maxpool3s2_bwd_f16");
 }
 extern "C" int shdr_resize2x_fwd_f16(const void* x, void* y, int N, int H, int W, int C, void* stream) {

@@ -167,6 +167,25 @@ def test_pool_resize_gap_backward_parity(shdr):
     assert rel_err(host(dx.grad), tx.grad.numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("shape", [(2, 16, 12, 16), (1, 7, 9, 8), (1, 1, 1, 8), (1, 2, 3, 8)])
+def test_maxpool3s2_backward_ties_go_to_the_first_maximum(shdr, half, shape):
+    """post-ReLU maps are full of equal values: the gradient of a window goes to its FIRST maximum in scan order, as
+    tf.nn.max_pool's CPU gradient and the oracle do, and to nobody else.  Values drawn from {0,1,2} tie in most windows."""
+    rng = np.random.default_rng(shape[1] * 31 + shape[2])
+    K = shdr._ops
+    x = f32(rng.integers(0, 3, size=shape))
+    tx = R.T(x, True)
+    ty = R.max_pool(tx, 3, 2)
+    gy = f32(rng.integers(-4, 5, size=tuple(ty.shape)))          # small integers: the sums are exact in fp16 too
+    (ty * R.T(gy)).sum().backward()
+    dx = dev(x).half().requires_grad_(True) if half else dev(x, True)
+    y = K.maxpool3s2(dx)
+    (y.float() * dev(gy)).sum().backward()
+    np.testing.assert_array_equal(host(dx.grad.float()), tx.grad.numpy())
+    assert float(dx.grad.float().sum()) == float(gy.sum())      # every window's gradient lands exactly once
+
+
 def test_crf_head_backward_parity(shdr, emor_table):
     rng = np.random.default_rng(8)
     K = shdr._ops
