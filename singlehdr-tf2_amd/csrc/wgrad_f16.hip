@@ -51,15 +51,20 @@ __host__ __device__ constexpr int win_swz(int p) {
 
 constexpr int pick_wm(int tm, int tn) { return (tm >= 2 && (tn >= 2 || tm >= 4)) ? (tn >= 2 ? 2 : 4) : (tm >= 2 && tn == 1 ? (tm >= 4 ? 4 : 2) : 1); }
 
-template <int CI_T, int CO_T, int KC>
-__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(const WgradHArgs a) {
+// NWV = 4 waves, two blocks per CU (tiles up to 128 x 128), or NWV = 8 waves and ONE block per CU for the 256-wide tiles: the
+// per-tap kernel streams (CI_T + CO_T) * 64 bytes per 32-pixel chunk from L2 for CI_T * CO_T * 64 flop, i.e. 64 flop/B at 128 x 128
+// -- 530-650 TFLOP/s measured is what ~9 TB/s of L2 -> LDS traffic gives -- and 128 flop/B at 256 x 256.
+template <int CI_T, int CO_T, int KC, int NWV = 4, int WM_ = 0>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void wgrad_f16_kernel(const WgradHArgs a) {
   constexpr int TM = CI_T / 16, TN = CO_T / 16;
-  constexpr int WM = pick_wm(TM, TN);
-  constexpr int WN = (4 / WM) < TN ? (4 / WM) : TN;
+  constexpr int WM = WM_ ? WM_ : pick_wm(TM, TN);
+  constexpr int WN = (NWV / WM) < TN ? (NWV / WM) : TN;
   constexpr int MT = TM / WM, NT = TN / WN;
   static_assert(MT * WM == TM && NT * WN == TN, "wave tiles must cover the block tile");
+  constexpr bool PER_CHUNK = (MT + NT) * KC > 16;                    // fragments of one chunk at a time: the accumulators need the registers
+  static_assert(!PER_CHUNK || WM * WN == NWV, "the per-chunk loop has every wave computing");
   constexpr int XI_TOTAL = CI_T / 16, ZI_TOTAL = CO_T / 16;          // wave DMA instructions per chunk (1 KiB each)
-  constexpr int XI = (XI_TOTAL + 3) / 4, ZI = (ZI_TOTAL + 3) / 4;
+  constexpr int XI = (XI_TOTAL + NWV - 1) / NWV, ZI = (ZI_TOTAL + NWV - 1) / NWV;
   constexpr int XP = CI_T / 8, ZP = CO_T / 8;                        // 16-byte pieces per pixel row
   constexpr int CHUNK_HALVES = PK * (CI_T + CO_T);
   constexpr int STAGE_HALVES = KC * CHUNK_HALVES;
@@ -184,6 +189,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(const WgradHArgs a) {
 #pragma unroll 1
   for (int st = 0; st < nstages; ++st) {
     _Float16* base = hsm + (st & 1) * STAGE_HALVES;
+    if constexpr (PER_CHUNK) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        Frag xa[MT], zb[NT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          xa[mi].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + c * CHUNK_HALVES + x_rd[0][mi]));
+          xa[mi].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + c * CHUNK_HALVES + x_rd[1][mi]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          zb[ni].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + c * CHUNK_HALVES + z_rd[0][ni]));
+          zb[ni].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + c * CHUNK_HALVES + z_rd[1][ni]));
+        }
+        if (c == 0 && st + 1 < nstages) dma_stage((st + 1) & 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[mi].v, zb[ni].v, acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __syncthreads();
+      continue;
+    }
     Frag xa[KC][MT], zb[KC][NT];
     if (computing) {
 #pragma unroll
@@ -233,30 +264,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(const WgradHArgs a) {
   }
 }
 
-template <int CI_T, int CO_T>
+template <int CI_T, int CO_T, int NWV = 4, int WM_ = 0>
 int launch_wgrad_f16(WgradHArgs& a, hipStream_t st) {
   constexpr int KC = (CI_T + CO_T) <= 128 ? 4 : 2;                   // >= 16 KiB per stage
   constexpr int lds = 2 * KC * PK * (CI_T + CO_T) * 2;
   a.tiles_m = (a.Cx + CI_T - 1) / CI_T;
   a.tiles_n = (a.Cz + CO_T - 1) / CO_T;
   const long tiles = (long)a.KH * a.KW * a.tiles_m * a.tiles_n;
-  // pixel slices: enough blocks to fill the chip a few times over, slices of at least 2048 pixels (atomics per block are fixed)
-  long want = (4L * 256 + tiles - 1) / tiles;
-  long slice = (a.npix + want - 1) / want;
-  if (slice < 2048) slice = 2048;
+  // Pixel slices.  Every block pays a DMA prologue and CI_T x CO_T atomics, so the grid is cut to fill whole ROUNDS of the chip's
+  // block slots (CUs x the kernel's occupancy) -- ONE round unless SHDR_WGRAD_ROUNDS says otherwise:
+  // one round of 252 blocks ran the 256 x 256 tile at 821-950 TFLOP/s where four rounds of 1008 ran at 676-843, and a grid of
+  // 1029 blocks on 512 slots (the 7x7 stem) spent a third of its time in a round of 5 blocks.
+  static long slots_of[shdr::kMaxDevices] = {};
+  const int dev_slot = shdr::device_slot();
+  if (slots_of[dev_slot] == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel<CI_T, CO_T, KC, NWV, WM_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wgrad_f16_kernel<CI_T, CO_T, KC, NWV, WM_>, NWV * 64, lds) != hipSuccess ||
+        cus < 1 || occ < 1)
+      return shdr::fail(SHDR_E_ARCH, "wgrad_f16: occupancy query failed");
+    slots_of[dev_slot] = (long)cus * occ;
+  }
+  const long slots = slots_of[dev_slot];
+  int rounds = 1;
+  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atoi(e);
+  long slice = a.npix;
+  bool chosen = false;
+  for (int r = 1; r <= 64 && !(chosen && r > rounds); ++r) {
+    long ns = slots * r / tiles;
+    if (ns < 1) continue;
+    if (ns > a.npix / 1024) ns = a.npix >= 2048 ? a.npix / 1024 : 1;   // slices of >= 1024 pixels
+    const long sl = (a.npix + ns - 1) / ns;
+    if (sl >= 1536 || !chosen) slice = sl;
+    chosen = true;
+  }
   slice = (slice + KC * PK - 1) / (KC * PK) * (KC * PK);
   a.slice = (int)slice;
   const long nslices = (a.npix + slice - 1) / slice;
   if (tiles * nslices > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "wgrad_f16: grid too large");
-  static bool attr_done[shdr::kMaxDevices] = {};
-  const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel<CI_T, CO_T, KC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done[dev_slot] = true;
-  }
-  hipLaunchKernelGGL((wgrad_f16_kernel<CI_T, CO_T, KC>), dim3((unsigned)(tiles * nslices)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_f16_kernel<CI_T, CO_T, KC, NWV, WM_>), dim3((unsigned)(tiles * nslices)), dim3(NWV * 64), lds, st, a);
   return shdr::check_launch("wgrad_f16_kernel");
 }
 
@@ -306,6 +355,15 @@ extern "C" int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, i
   a.npix = d->N * d->Ho * d->Wo;
   a.x_scale = which ? d->x2_scale : 1.0f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // 256-wide tiles (8 waves, one block per CU) halve the L2 -> LDS traffic per flop of the widest layers
+  long min256 = 4096;
+  if (const char* e = getenv("SHDR_WGRAD_256_MIN_PIXELS")) min256 = atol(e);
+  if (getenv("SHDR_NO_WGRAD_256") == nullptr && a.npix >= min256) {
+    const bool one = a.KH * a.KW == 1;                           // 1x1: few pixels per block, only the widest pay (0.128 -> 0.115 ms at 1024 -> 512)
+    if (Cx % 256 == 0 && a.Cz % 256 == 0) return launch_wgrad_f16<256, 256, 8, 4>(a, st);
+    if (Cx % 256 == 0 && a.Cz % 128 == 0 && !one) return launch_wgrad_f16<256, 128, 8, 4>(a, st);
+    if (Cx % 128 == 0 && a.Cz % 256 == 0 && !one) return launch_wgrad_f16<128, 256, 8, 2>(a, st);
+  }
   if (Cx % 128 == 0) return dispatch_co<128>(a, st);
   // 96 input channels (the Linearization-Net stem, 7x7 / 2): ONE ci tile, so dZ is streamed once per tap instead of three times
   // (the 134 MB gradient of the 4 x 1024^2 step: 2.97 -> ms with three 32-channel tiles)

@@ -54,6 +54,11 @@ CASES = [
     ("unet_3x3_64_32_lrelu", 1, 24, 40, 64, 0, 32, 3, 1, 2, 1.0),
     ("w3_concat_64_64_128_ragged", 2, 21, 37, 64, 64, 128, 3, 1, 2, 1.0),      # two sources, ragged tile edges
     ("w3_3x3_32_64", 1, 48, 48, 32, 0, 64, 3, 1, 1, 1.0),                      # a single 32-channel chunk
+    ("wgrad256_3x3_256_256", 2, 18, 22, 256, 0, 256, 3, 1, 1, 1.0),            # 8-wave 256 x 256 weight-gradient tile, ragged slices
+    ("wgrad256_3x3_512_256", 1, 19, 21, 512, 0, 256, 3, 1, 0, 1.0),            # two ci tiles
+    ("wgrad256_3x3_128_256", 1, 16, 24, 128, 0, 256, 3, 1, 2, 1.0),            # 128 x 256 tile
+    ("wgrad256_concat_256_256_128", 1, 16, 20, 256, 256, 128, 3, 1, 2, 1.0),   # 256 x 128 tile, two sources
+    ("wgrad256_1x1_1024_512", 1, 12, 12, 1024, 0, 512, 1, 1, 0, 1.0),
 ]
 
 
@@ -66,6 +71,7 @@ def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case, kernels,
     name, n, h, w, c1, c2, cout, k, stride, act, x2s = case
     if kernels == "specialised":
         monkeypatch.setenv("SHDR_ALLTAPS_MIN_PIXELS", "0")
+        monkeypatch.setenv("SHDR_WGRAD_256_MIN_PIXELS", "0")    # the 256-wide weight-gradient tiles at these small shapes too
         monkeypatch.setenv("SHDR_W3_MIN_BLOCKS", "0")             # wide 3x3 layers: the patch-per-chunk kernel (conv_f16_w3.hip)
     else:
         monkeypatch.setenv("SHDR_NO_PATCH", "1")

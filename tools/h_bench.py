@@ -18,11 +18,12 @@ SHAPES = [  # n, h, w, c1, c2, cout, k, stride
     (4, 1024, 1024, 16, 0, 16, 7, 1), (4, 1024, 1024, 8, 0, 16, 7, 1), (4, 1024, 1024, 32, 0, 16, 3, 1),
     (4, 1024, 1024, 16, 16, 16, 3, 1), (4, 512, 512, 16, 0, 32, 5, 1), (4, 512, 512, 32, 0, 32, 5, 1),
     (4, 1024, 1024, 96, 0, 64, 7, 2), (4, 256, 256, 64, 0, 256, 1, 1), (4, 256, 256, 256, 0, 64, 1, 1),
-    (4, 1024, 1024, 16, 0, 64, 3, 1),
+    (4, 1024, 1024, 16, 0, 64, 3, 1), (4, 64, 64, 512, 0, 512, 3, 1), (4, 128, 128, 256, 0, 512, 3, 1), (4, 256, 256, 128, 0, 256, 3, 1),
+    (4, 128, 128, 1024, 0, 512, 1, 1), (4, 128, 128, 128, 0, 512, 1, 1), (4, 128, 128, 512, 0, 128, 1, 1),
 ]
 
 
-def timeit(fn, reps=5):
+def timeit(fn, reps=20):
     for _ in range(2):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,6 +36,8 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "wide":       # the layers of the 256-wide weight-gradient tiles
+    SHAPES = [t for t in SHAPES if (t[3] + t[4]) % 128 == 0 and t[5] % 128 == 0 and (t[3] + t[4] >= 256 or t[5] >= 256)]
 for n, h, w, c1, c2, cout, k, s in SHAPES:
     x = torch.randn(n, h, w, c1, device="cuda").half()
     x2 = torch.randn(n, h, w, c2, device="cuda").half() if c2 else None
