@@ -53,11 +53,18 @@ struct AG {
   static constexpr int XJ = ((X_PIECES + 63) / 64 + 3) / 4, ZJ = ((Z_PIECES + 63) / 64 + 3) / 4;   // DMA instructions per wave
   static constexpr int X_HALVES = XJ * 4 * 512, Z_HALVES = ZJ * 4 * 512;
   static constexpr int STAGE_HALVES = X_HALVES + Z_HALVES;
-  static constexpr int LDS_BYTES = 2 * STAGE_HALVES * 2;
+  static constexpr int STAGE_BYTES = STAGE_HALVES * 2;
+  static constexpr int NST = 4 * STAGE_BYTES < 80 * 1024 ? 4 : 3;     // ring of segment stages: two blocks per CU keep their 160 KB
+  static constexpr int DPS = XJ + ZJ;                                 // DMA instructions per wave and stage
+  static constexpr int LDS_BYTES = NST * STAGE_BYTES;
 };
 
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
+constexpr int vmcnt_only(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+constexpr int lgkmcnt_only(int n) { return 0xC07F | (n << 8); }
+
 template <int KK, int CI_T, int CO_T, int MODE>
-__global__ __launch_bounds__(256) void wgrad_f16_alltaps_kernel(const WgradAArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAArgs a) {
   using G = AG<KK, CI_T, CO_T, MODE>;
   constexpr int MT = G::MT, NT = G::NT, PAD = (KK - 1) / 2;
   extern __shared__ __attribute__((aligned(16))) _Float16 asm_[];     // [2][ X strip | Z ]
@@ -132,48 +139,99 @@ __global__ __launch_bounds__(256) void wgrad_f16_alltaps_kernel(const WgradAArgs
     sv4 h[2];
     f16x8 v;
   };
-  int z_rd[2][NT];
+  // LDS byte addresses inside a stage.  The reads are inline asm: the compiler orders every LDS read it knows of behind ALL
+  // LDS-DMA writes in flight (s_waitcnt vmcnt(0) -- it cannot tell the ring's buffers apart), which would drain the ring once per
+  // segment; hidden in asm their completion is the counted "s_waitcnt lgkmcnt" + register fence in front of each MFMA group.
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)asm_;
+  unsigned z_rd[2][NT], x_rd[MODE ? KK : 1][2][MT];                    // MODE 0: the tap is a run-time value, its address is formed per read
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = 8 * g + 4 * h + q;
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) z_rd[h][ni] = G::X_HALVES + row * CO_T + 16 * ((wn * NT + ni) ^ wswz<CO_T>(row)) + 4 * pp;
-  }
-
-  if (s_begin < s_end) dma_seg(s_begin, 0);
-  int buf = 0;
-  for (int seg = s_begin; seg < s_end; ++seg, buf ^= 1) {
-    __syncthreads();
-    if (seg + 1 < s_end) dma_seg(seg + 1, buf ^ 1);
-    const _Float16* base = asm_ + buf * G::STAGE_HALVES;
-    Frag zb[NT];
+    for (int ni = 0; ni < NT; ++ni)
+      z_rd[h][ni] = lds0 + 2u * (unsigned)(G::X_HALVES + row * CO_T + 16 * ((wn * NT + ni) ^ wswz<CO_T>(row)) + 4 * pp);
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      zb[ni].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + z_rd[0][ni]));
-      zb[ni].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + z_rd[1][ni]));
+    for (int kw = 0; kw < (MODE ? KK : 1); ++kw) {
+      const int sp = row + kw;                                        // strip pixel of this lane's row
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) x_rd[kw][h][mi] = lds0 + 2u * (unsigned)(sp * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp);
     }
+  }
+  constexpr int ROW_BYTES = G::SW * CI_T * 2;                          // one strip row (the kh term is an immediate offset)
+  auto read_x = [&](Frag* xa, int tap, unsigned sbase) {
+    const int kh = tap / KK, kw = tap - kh * KK;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned ad;
+        if (MODE) {
+          ad = x_rd[kw][h][mi] + sbase + (unsigned)(kh * ROW_BYTES);
+        } else {
+          const int sp = 8 * g + 4 * h + q + kw;
+          ad = lds0 + sbase + 2u * (unsigned)((kh * G::SW + sp) * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp);
+        }
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[mi].h[h]) : "v"(ad));
+      }
+  };
+
+  if (s_begin >= s_end) return;
+  // Ring of NST stages: the DMA of segment s + NST - 1 is issued at the top of iteration s, so NST - 1 segments are in flight
+  // per block (a segment's MFMAs take ~0.3 us, an L2 / HBM round trip 1-2 us: with the two-stage ring the kernel waited for
+  // every segment).  "s_waitcnt vmcnt((NST - 2) * DPS)" at the bottom = this wave's pieces of segment s + 1 have landed, the
+  // barrier after it = everybody's; the DMA count per wave and iteration is uniform (past the end the last segment is re-fetched).
+#pragma unroll
+  for (int i = 0; i < G::NST - 1; ++i) dma_seg(min(s_begin + i, s_end - 1), i);
+  __builtin_amdgcn_s_waitcnt(vmcnt_only((G::NST - 2) * G::DPS));
+  __builtin_amdgcn_s_barrier();
+  int rb = 0, wb = G::NST - 1;
+#pragma unroll 1
+  for (int seg = s_begin; seg < s_end; ++seg) {
+    dma_seg(min(seg + G::NST - 1, s_end - 1), wb);
+    const unsigned sbase = (unsigned)(rb * G::STAGE_BYTES);
+    Frag zb[NT], xa[2][MT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned ad = z_rd[h][ni] + sbase;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(zb[ni].h[h]) : "v"(ad));
+      }
+    const int tap0 = MODE ? 0 : wave;
+    if (MODE || tap0 < G::NTAPS) read_x(xa[0], tap0, sbase);
 #pragma unroll
     for (int t = 0; t < G::TAPS_W; ++t) {
       const int tap = MODE ? t : 4 * t + wave;                       // wave-uniform
+      const int nxt = MODE ? t + 1 : 4 * (t + 1) + wave;
+      const bool more = t + 1 < G::TAPS_W && (MODE || nxt < G::NTAPS);
       if (MODE || tap < G::NTAPS) {
-        const int kh = tap / KK, kw = tap - kh * KK;
-        Frag xa[MT];
+        if (more) {                                                   // the next tap's operand reads run under this tap's MFMAs
+          read_x(xa[(t + 1) & 1], nxt, sbase);
+          __builtin_amdgcn_s_waitcnt(lgkmcnt_only(2 * MT));
+        } else {
+          __builtin_amdgcn_s_waitcnt(lgkmcnt_only(0));
+        }
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(xa[t & 1][mi].v));
+        if (t == 0) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int sp = 8 * g + 4 * h + q + kw;                    // strip pixel of this lane's row
-            const int off = (kh * G::SW + sp) * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp;
-            xa[mi].h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lsv4_t)(base + off));
-          }
+          for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(zb[ni].v));
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni)
-            acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[mi].v, zb[ni].v, acc[t][mi][ni], 0, 0, 0);
+            acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[t & 1][mi].v, zb[ni].v, acc[t][mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
+    __builtin_amdgcn_s_waitcnt(vmcnt_only((G::NST - 2) * G::DPS) & lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+    rb = rb + 1 == G::NST ? 0 : rb + 1;
+    wb = wb + 1 == G::NST ? 0 : wb + 1;
   }
+  __builtin_amdgcn_s_waitcnt(vmcnt_only(0));                          // the re-fetched tail segments land before the block's LDS is released
 
   // D[ci][co]: lane holds column co = lane & 15 of rows ci = 4 * (lane >> 4) + e
   const int fi = lane & 15, fg = lane >> 4;
@@ -204,21 +262,30 @@ int launch_alltaps(WgradAArgs& a, hipStream_t st) {
   const long tiles = (long)tiles_m * a.tiles_n;
   a.segs_x = (a.W + 31) / 32;
   a.nsegs = a.N * a.H * a.segs_x;
-  // segment slices: fill the chip a few times over; at least 64 segments (2048 pixels) per block so that the atomics stay cheap
-  long want = (4L * 256 + tiles - 1) / tiles;
-  long slice = (a.nsegs + want - 1) / want;
-  if (slice < 64) slice = 64;
-  a.slice = (int)slice;
-  const long nslices = (a.nsegs + slice - 1) / slice;
-  if (nslices > 65535) return shdr::fail(SHDR_E_SHAPE, "wgrad_f16_alltaps: grid too large");
-  static bool attr_done[shdr::kMaxDevices] = {};
+  // segment slices: ONE round of the chip's block slots (CUs x occupancy; wgrad_f16.hip has the measurements), at least 32
+  // segments (1024 pixels) per block so that the KK^2 x CI_T x CO_T atomics of a block stay cheap
+  static long slots_of[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
+  if (slots_of[dev_slot] == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_alltaps_kernel<KK, CI_T, CO_T, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done[dev_slot] = true;
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wgrad_f16_alltaps_kernel<KK, CI_T, CO_T, MODE>, 256, G::LDS_BYTES) != hipSuccess ||
+        cus < 1 || occ < 1)
+      return shdr::fail(SHDR_E_ARCH, "wgrad_f16_alltaps: occupancy query failed");
+    slots_of[dev_slot] = (long)cus * occ;
   }
+  long rounds = 1;
+  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
+  long want = slots_of[dev_slot] * rounds / tiles;
+  if (want < 1) want = 1;
+  long slice = (a.nsegs + want - 1) / want;
+  if (slice < 32) slice = 32;
+  a.slice = (int)slice;
+  const long nslices = (a.nsegs + slice - 1) / slice;
+  if (nslices > 65535) return shdr::fail(SHDR_E_SHAPE, "wgrad_f16_alltaps: grid too large");
   hipLaunchKernelGGL((wgrad_f16_alltaps_kernel<KK, CI_T, CO_T, MODE>), dim3((unsigned)tiles, (unsigned)nslices), dim3(256), G::LDS_BYTES, st, a);
   return shdr::check_launch("wgrad_f16_alltaps_kernel");
 }
