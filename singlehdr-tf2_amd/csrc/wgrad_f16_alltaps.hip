@@ -31,7 +31,7 @@ struct WgradAArgs {
   const _Float16* dz;  // [N,H,W,Cz]
   float* dw;           // [KK*KK][Ct][Cout]
   int N, H, W, Cx, Cz, Ct, ci_off, Cout;
-  int segs_x, nsegs, slice, tiles_n;
+  int segs_x, nsegs, slice, tiles_n, col_order;
   int ci_valid, co_valid;
   float x_scale;
 };
@@ -100,11 +100,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAA
     zok[j] = zok[j] && co0 + zc[j] < a.Cz;
   }
   auto dma_seg = [&](int seg, int buf) {
-    int t = seg;
-    const int sx = t % a.segs_x;
-    t /= a.segs_x;
-    const int oh = t % a.H;
-    const int n = t / a.H;
+    // segments run DOWN a 32-pixel column: consecutive segments of a block share KK - 1 of their KK strip rows, which the
+    // XCD's L2 still holds (walking along a row the re-read came 1024 pixels later, from the Infinity Cache or HBM)
+    int sx, oh, n;
+    if (a.col_order) {
+      oh = seg % a.H;
+      const int t = seg / a.H;
+      sx = t % a.segs_x;
+      n = t / a.segs_x;
+    } else {
+      sx = seg % a.segs_x;
+      const int t = seg / a.segs_x;
+      oh = t % a.H;
+      n = t / a.H;
+    }
     const int ow0 = sx * 32;
     _Float16* Xb = asm_ + buf * G::STAGE_HALVES;
     _Float16* Zb = Xb + G::X_HALVES;
@@ -261,6 +270,7 @@ int launch_alltaps(WgradAArgs& a, hipStream_t st) {
   a.tiles_n = (a.Cz + CO_T - 1) / CO_T;
   const long tiles = (long)tiles_m * a.tiles_n;
   a.segs_x = (a.W + 31) / 32;
+  a.col_order = getenv("SHDR_ALLTAPS_ROW_ORDER") == nullptr;
   a.nsegs = a.N * a.H * a.segs_x;
   // segment slices: ONE round of the chip's block slots (CUs x occupancy; wgrad_f16.hip has the measurements), at least 32
   // segments (1024 pixels) per block so that the KK^2 x CI_T x CO_T atomics of a block stay cheap
