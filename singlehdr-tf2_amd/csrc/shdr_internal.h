@@ -1,6 +1,7 @@
 // Internal helpers shared by the libshdr translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -51,6 +52,27 @@ inline int stream_grid(int64_t work_items, int block = 256) {
   if (g < 1) g = 1;
   if (g > 256 * 8) g = 256 * 8;
   return static_cast<int>(g);
+}
+
+// Block slots of the chip for one kernel: CUs x the kernel's occupancy at this block size and dynamic LDS (0 on failure).
+// The split-K weight-gradient kernels cut their grids to ONE round of these slots: every block pays a prologue and a tile of
+// atomics, and a grid a few blocks over a whole round spends that round on a handful of CUs (wgrad_f16.hip has the measurements).
+template <typename KernelT>
+inline long block_slots(KernelT kernel, int threads, size_t lds) {
+  int dev = 0, cus = 0, occ = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || cus < 1 || occ < 1)
+    return 0;
+  return (long)cus * occ;
+}
+// slices (of `units` work items, at least `min_slice` each) per tile so that tiles x slices fills `rounds` rounds of the slots
+inline long slice_for_rounds(long slots, long tiles, long units, long min_slice) {
+  long rounds = 1;
+  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
+  long ns = slots * rounds / tiles;
+  if (ns < 1) ns = 1;
+  long slice = (units + ns - 1) / ns;
+  return slice < min_slice ? min_slice : slice;
 }
 
 // out[c] += sum over the g partial rows ws[b * C + c] (written by reduction kernels that give every block its own row instead

@@ -455,19 +455,23 @@ int launch_wgrad_prec(WgradArgs& a, hipStream_t st) {
   a.tiles_m = (a.Cx + BMc - 1) / BMc;
   a.tiles_n = (a.Cout + BNc - 1) / BNc;
   constexpr int lds = 2 * PK * (BMc + BNc) * 4;
-  static bool attr_done[shdr::kMaxDevices] = {};
+  static long slots_of[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
+  if (slots_of[dev_slot] == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<BMc, BNc, WM, WN, PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done[dev_slot] = true;
+    slots_of[dev_slot] = shdr::block_slots(wgrad_mfma_kernel<BMc, BNc, WM, WN, PREC>, 256, lds);
+    if (slots_of[dev_slot] == 0) return shdr::fail(SHDR_E_ARCH, "wgrad: occupancy query failed");
   }
-  // enough pixel slices to fill the chip ~4x, but at least 2048 pixels per slice to bound the atomics
+  // pixel slices: one round of the chip's block slots, at least 1024 pixels per slice to bound the atomics
   const long tiles = (long)a.KH * a.KW * a.tiles_m * a.tiles_n;
-  long want = (256L * 8 + tiles - 1) / tiles;
-  long slice = (a.npix + want - 1) / want;
-  if (slice < 2048) slice = 2048;
+  long slice = shdr::slice_for_rounds(slots_of[dev_slot], tiles, a.npix, 1024);
+  if (getenv("SHDR_WGRAD_LEGACY_GRID")) {
+    const long want = (256L * 8 + tiles - 1) / tiles;
+    slice = (a.npix + want - 1) / want;
+    if (slice < 2048) slice = 2048;
+  }
   slice = (slice + PK - 1) / PK * PK;
   a.slice = (int)slice;
   a.nslices = (int)((a.npix + slice - 1) / slice);

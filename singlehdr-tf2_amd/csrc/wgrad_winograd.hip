@@ -254,23 +254,27 @@ extern "C" int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, f
   // spills (measured 10 % slower even without the pipeline)
   a.tiles_m = Cx / 32;
   a.tiles_n = Cout / 64;
-  // enough unit slices to give every CU ~3 blocks over the launch, but >= 32 units (256 tiles) per block to bound the atomics
-  const long tiles = (long)a.tiles_m * a.tiles_n;
-  long want = (768 + tiles - 1) / tiles;
-  long slice = (a.units + want - 1) / want;
-  if (slice < 32) slice = 32;
-  a.slice = (int)slice;
-  const long nslices = (a.units + slice - 1) / slice;
-  SHDR_REQUIRE(nslices <= 65535, SHDR_E_SHAPE, "wgrad_winograd: too many unit slices");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static bool attr_done[shdr::kMaxDevices] = {};
+  static long slots_of[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
+  if (slots_of[dev_slot] == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_winograd_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WW<2>::LDS_BYTES);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done[dev_slot] = true;
+    slots_of[dev_slot] = shdr::block_slots(wgrad_winograd_kernel<2>, 256, WW<2>::LDS_BYTES);
+    if (slots_of[dev_slot] == 0) return shdr::fail(SHDR_E_ARCH, "wgrad_winograd: occupancy query failed");
   }
+  // unit slices: one round of the chip's block slots, >= 32 units (256 tiles) per block to bound the atomics
+  const long tiles = (long)a.tiles_m * a.tiles_n;
+  long slice = shdr::slice_for_rounds(slots_of[dev_slot], tiles, a.units, 32);
+  if (getenv("SHDR_WGRAD_LEGACY_GRID")) {
+    const long want = (768 + tiles - 1) / tiles;
+    slice = (a.units + want - 1) / want;
+    if (slice < 32) slice = 32;
+  }
+  a.slice = (int)slice;
+  const long nslices = (a.units + slice - 1) / slice;
+  SHDR_REQUIRE(nslices <= 65535, SHDR_E_SHAPE, "wgrad_winograd: too many unit slices");
   hipLaunchKernelGGL(wgrad_winograd_kernel<2>, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), WW<2>::LDS_BYTES, st, a);
   if (int rc = shdr::check_launch("wgrad_winograd_kernel")) return rc;
   hipLaunchKernelGGL(winograd_dw_kernel, dim3(shdr::stream_grid((long)Cx * Cout)), dim3(256), 0, st, du, dw, Cx, Cout, Ct, ci_off,
