@@ -13,6 +13,9 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -31,7 +34,7 @@ struct WgradAArgs {
   const _Float16* dz;  // [N,H,W,Cz]
   float* dw;           // [KK*KK][Ct][Cout]
   int N, H, W, Cx, Cz, Ct, ci_off, Cout;
-  int segs_x, nsegs, slice, tiles_n, col_order;
+  int segs_x, nsegs, slice, tiles_n;
   int ci_valid, co_valid;
   float x_scale;
 };
@@ -63,6 +66,21 @@ struct AG {
 constexpr int vmcnt_only(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 constexpr int lgkmcnt_only(int n) { return 0xC07F | (n << 8); }
 
+// ds_read_b64_tr_b16 with an immediate byte offset, outside the compiler's view of LDS (see the kernel)
+template <int OFF>
+__device__ __forceinline__ sv4 ld_tr(unsigned addr) {
+  sv4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int T0, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (T0 < N) {
+    f(std::integral_constant<int, T0>{});
+    static_for<T0 + 1, N>(f);
+  }
+}
+
 template <int KK, int CI_T, int CO_T, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAArgs a) {
   using G = AG<KK, CI_T, CO_T, MODE>;
@@ -78,16 +96,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAA
   const _Float16* zero = reinterpret_cast<const _Float16*>(g_wa_zero_page);
 
   // ---- DMA geometry: piece -> (strip row, strip pixel, logical 16-byte piece) -------------------------------------------------
-  int xr[G::XJ], xs[G::XJ], xc[G::XJ], zp[G::ZJ], zc[G::ZJ];
+  // Segments run DOWN a 32-pixel column (consecutive segments of a block share KK - 1 of their KK strip rows, which the XCD's L2
+  // still holds; walking along a row the re-read came 1024 pixels later, from the Infinity Cache or HBM), so from one segment
+  // to the next every piece's source moves by exactly one image row: the element offsets are kept per lane and advanced by a
+  // constant, and rebuilt only where the column ends (the per-segment address arithmetic -- two divisions, 64-bit multiplies
+  // and bounds tests per piece -- was a third of the loop's vector instructions, and the loop is bound by vector issue).
+  int xrp[G::XJ], xsp[G::XJ], xc[G::XJ], zp[G::ZJ], zc[G::ZJ];      // strip row / pixel relative to the segment's first output pixel
   bool xok[G::XJ], zok[G::ZJ];
 #pragma unroll
   for (int j = 0; j < G::XJ; ++j) {
     const int piece = (wave * G::XJ + j) * 64 + lane;
     xok[j] = piece < G::X_PIECES;
     const int pix = piece / G::XP, pq = piece - pix * G::XP;
-    xr[j] = pix / G::SW;
-    xs[j] = pix - xr[j] * G::SW;
-    xc[j] = 8 * ((((pq >> 1) ^ wswz<CI_T>(xs[j])) << 1) | (pq & 1));
+    const int r = pix / G::SW, sp = pix - r * G::SW;
+    xrp[j] = r - PAD;
+    xsp[j] = sp - PAD;
+    xc[j] = 8 * ((((pq >> 1) ^ wswz<CI_T>(sp)) << 1) | (pq & 1));
     xok[j] = xok[j] && ci0 + xc[j] < a.Cx;
   }
 #pragma unroll
@@ -99,37 +123,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAA
     zc[j] = 8 * ((((pq >> 1) ^ wswz<CO_T>(zp[j])) << 1) | (pq & 1));
     zok[j] = zok[j] && co0 + zc[j] < a.Cz;
   }
-  auto dma_seg = [&](int seg, int buf) {
-    // segments run DOWN a 32-pixel column: consecutive segments of a block share KK - 1 of their KK strip rows, which the
-    // XCD's L2 still holds (walking along a row the re-read came 1024 pixels later, from the Infinity Cache or HBM)
-    int sx, oh, n;
-    if (a.col_order) {
-      oh = seg % a.H;
-      const int t = seg / a.H;
-      sx = t % a.segs_x;
-      n = t / a.segs_x;
-    } else {
-      sx = seg % a.segs_x;
-      const int t = seg / a.segs_x;
-      oh = t % a.H;
-      n = t / a.H;
-    }
+  // element offsets modulo 2^32 (the host checks N*H*W*C < 2^32; rows above the image wrap and are never dereferenced)
+  unsigned xoff[G::XJ], zoff[G::ZJ];
+  bool xcol[G::XJ], zcol[G::ZJ];
+  int d_seg = s_begin, d_oh = 0;                                      // the next segment to fetch and its image row
+  const unsigned rowx = (unsigned)(a.W * a.Cx), rowz = (unsigned)(a.W * a.Cz);
+  auto dma_column = [&]() {
+    d_oh = d_seg % a.H;
+    const int t = d_seg / a.H;
+    const int sx = t % a.segs_x, n = t / a.segs_x;
     const int ow0 = sx * 32;
-    _Float16* Xb = asm_ + buf * G::STAGE_HALVES;
-    _Float16* Zb = Xb + G::X_HALVES;
 #pragma unroll
     for (int j = 0; j < G::XJ; ++j) {
-      const int ih = oh - PAD + xr[j], iw = ow0 - PAD + xs[j];
-      const bool ok = xok[j] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      const _Float16* src = ok ? a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.Cx + ci0 + xc[j] : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xb + (wave * G::XJ + j) * 512), 16, 0, 0);
+      const int iw = ow0 + xsp[j];
+      xcol[j] = xok[j] && (unsigned)iw < (unsigned)a.W;
+      xoff[j] = ((unsigned)(n * a.H + d_oh + xrp[j]) * (unsigned)a.W + (unsigned)iw) * (unsigned)a.Cx + (unsigned)(ci0 + xc[j]);
     }
 #pragma unroll
     for (int j = 0; j < G::ZJ; ++j) {
       const int ow = ow0 + zp[j];
-      const bool ok = zok[j] && ow < a.W;
-      const _Float16* src = ok ? a.dz + ((size_t)(n * a.H + oh) * a.W + ow) * a.Cz + co0 + zc[j] : zero;
+      zcol[j] = zok[j] && ow < a.W;
+      zoff[j] = ((unsigned)(n * a.H + d_oh) * (unsigned)a.W + (unsigned)ow) * (unsigned)a.Cz + (unsigned)(co0 + zc[j]);
+    }
+  };
+  // fetch segment d_seg into stage `buf` and step to the next one (past the slice's end the last segment is fetched again: the
+  // DMA count per wave and iteration stays uniform for the counted waits)
+  auto dma_next = [&](int buf) {
+    _Float16* Xb = asm_ + buf * G::STAGE_HALVES;
+    _Float16* Zb = Xb + G::X_HALVES;
+#pragma unroll
+    for (int j = 0; j < G::XJ; ++j) {
+      const bool ok = xcol[j] && (unsigned)(d_oh + xrp[j]) < (unsigned)a.H;
+      const _Float16* src = ok ? a.x + (size_t)xoff[j] : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xb + (wave * G::XJ + j) * 512), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < G::ZJ; ++j) {
+      const _Float16* src = zcol[j] ? a.dz + (size_t)zoff[j] : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Zb + (wave * G::ZJ + j) * 512), 16, 0, 0);
+    }
+    if (d_seg + 1 < s_end) {
+      ++d_seg;
+      if (++d_oh == a.H) {
+        dma_column();
+      } else {
+#pragma unroll
+        for (int j = 0; j < G::XJ; ++j) xoff[j] += rowx;
+#pragma unroll
+        for (int j = 0; j < G::ZJ; ++j) zoff[j] += rowz;
+      }
     }
   };
 
@@ -151,8 +193,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAA
   // LDS byte addresses inside a stage.  The reads are inline asm: the compiler orders every LDS read it knows of behind ALL
   // LDS-DMA writes in flight (s_waitcnt vmcnt(0) -- it cannot tell the ring's buffers apart), which would drain the ring once per
   // segment; hidden in asm their completion is the counted "s_waitcnt lgkmcnt" + register fence in front of each MFMA group.
+  // The stage (and in MODE 1 the tap's kh row) is the instruction's immediate offset: the ring is unrolled over its NST stages.
   const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)asm_;
-  unsigned z_rd[2][NT], x_rd[MODE ? KK : 1][2][MT];                    // MODE 0: the tap is a run-time value, its address is formed per read
+  constexpr int XR = MODE ? KK : G::TAPS_W;                           // MODE 1: per kw (+ immediate kh row); MODE 0: per tap of this wave
+  constexpr int ROW_BYTES = G::SW * CI_T * 2;
+  unsigned z_rd[2][NT], x_rd[XR][2][MT];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = 8 * g + 4 * h + q;
@@ -160,85 +205,87 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_alltaps_kernel(const WgradAA
     for (int ni = 0; ni < NT; ++ni)
       z_rd[h][ni] = lds0 + 2u * (unsigned)(G::X_HALVES + row * CO_T + 16 * ((wn * NT + ni) ^ wswz<CO_T>(row)) + 4 * pp);
 #pragma unroll
-    for (int kw = 0; kw < (MODE ? KK : 1); ++kw) {
+    for (int i = 0; i < XR; ++i) {
+      const int tap = MODE ? i : min(4 * i + wave, G::NTAPS - 1);
+      const int kh = MODE ? 0 : tap / KK, kw = MODE ? i : tap - kh * KK;
       const int sp = row + kw;                                        // strip pixel of this lane's row
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) x_rd[kw][h][mi] = lds0 + 2u * (unsigned)(sp * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp);
+      for (int mi = 0; mi < MT; ++mi)
+        x_rd[i][h][mi] = lds0 + 2u * (unsigned)((kh * G::SW + sp) * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp);
     }
   }
-  constexpr int ROW_BYTES = G::SW * CI_T * 2;                          // one strip row (the kh term is an immediate offset)
-  auto read_x = [&](Frag* xa, int tap, unsigned sbase) {
-    const int kh = tap / KK, kw = tap - kh * KK;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        unsigned ad;
-        if (MODE) {
-          ad = x_rd[kw][h][mi] + sbase + (unsigned)(kh * ROW_BYTES);
-        } else {
-          const int sp = 8 * g + 4 * h + q + kw;
-          ad = lds0 + sbase + 2u * (unsigned)((kh * G::SW + sp) * CI_T + 16 * ((wm * MT + mi) ^ wswz<CI_T>(sp)) + 4 * pp);
-        }
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[mi].h[h]) : "v"(ad));
-      }
-  };
 
   if (s_begin >= s_end) return;
   // Ring of NST stages: the DMA of segment s + NST - 1 is issued at the top of iteration s, so NST - 1 segments are in flight
   // per block (a segment's MFMAs take ~0.3 us, an L2 / HBM round trip 1-2 us: with the two-stage ring the kernel waited for
   // every segment).  "s_waitcnt vmcnt((NST - 2) * DPS)" at the bottom = this wave's pieces of segment s + 1 have landed, the
-  // barrier after it = everybody's; the DMA count per wave and iteration is uniform (past the end the last segment is re-fetched).
+  // barrier after it = everybody's.
+  dma_column();
 #pragma unroll
-  for (int i = 0; i < G::NST - 1; ++i) dma_seg(min(s_begin + i, s_end - 1), i);
+  for (int i = 0; i < G::NST - 1; ++i) dma_next(i);
   __builtin_amdgcn_s_waitcnt(vmcnt_only((G::NST - 2) * G::DPS));
   __builtin_amdgcn_s_barrier();
-  int rb = 0, wb = G::NST - 1;
-#pragma unroll 1
-  for (int seg = s_begin; seg < s_end; ++seg) {
-    dma_seg(min(seg + G::NST - 1, s_end - 1), wb);
-    const unsigned sbase = (unsigned)(rb * G::STAGE_BYTES);
-    Frag zb[NT], xa[2][MT];
+
+  // one segment from stage RB; operand reads run two taps ahead of the MFMAs (xa is a ring of three)
+  auto segment = [&](auto rbc) {
+    constexpr int RB = decltype(rbc)::value;
+    constexpr int SOFF = RB * G::STAGE_BYTES;
+    dma_next((RB + G::NST - 1) % G::NST);
+    Frag zb[NT], xa[3][MT];
+    auto read_x = [&](Frag* dst, auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int i = MODE ? t % KK : t;
+      constexpr int off = SOFF + (MODE ? (t / KK) * ROW_BYTES : 0);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dst[mi].h[h] = ld_tr<off>(x_rd[i][h][mi]);
+    };
+    auto valid = [&](int t) { return MODE || 4 * t + wave < G::NTAPS; };       // wave-uniform, monotone in t
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const unsigned ad = z_rd[h][ni] + sbase;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(zb[ni].h[h]) : "v"(ad));
+      for (int h = 0; h < 2; ++h) zb[ni].h[h] = ld_tr<SOFF>(z_rd[h][ni]);
+    if (valid(0)) read_x(xa[0], std::integral_constant<int, 0>{});
+    if (G::TAPS_W > 1 && valid(1)) read_x(xa[1], std::integral_constant<int, (G::TAPS_W > 1 ? 1 : 0)>{});
+    auto tap_step = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (!valid(t)) return;
+      if (t + 2 < G::TAPS_W && valid(t + 2)) {
+        read_x(xa[(t + 2) % 3], std::integral_constant<int, (t + 2 < G::TAPS_W ? t + 2 : 0)>{});
+        __builtin_amdgcn_s_waitcnt(lgkmcnt_only(4 * MT));
+      } else if (t + 1 < G::TAPS_W && valid(t + 1)) {
+        __builtin_amdgcn_s_waitcnt(lgkmcnt_only(2 * MT));
+      } else {
+        __builtin_amdgcn_s_waitcnt(lgkmcnt_only(0));
       }
-    const int tap0 = MODE ? 0 : wave;
-    if (MODE || tap0 < G::NTAPS) read_x(xa[0], tap0, sbase);
 #pragma unroll
-    for (int t = 0; t < G::TAPS_W; ++t) {
-      const int tap = MODE ? t : 4 * t + wave;                       // wave-uniform
-      const int nxt = MODE ? t + 1 : 4 * (t + 1) + wave;
-      const bool more = t + 1 < G::TAPS_W && (MODE || nxt < G::NTAPS);
-      if (MODE || tap < G::NTAPS) {
-        if (more) {                                                   // the next tap's operand reads run under this tap's MFMAs
-          read_x(xa[(t + 1) & 1], nxt, sbase);
-          __builtin_amdgcn_s_waitcnt(lgkmcnt_only(2 * MT));
-        } else {
-          __builtin_amdgcn_s_waitcnt(lgkmcnt_only(0));
-        }
+      for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(xa[t % 3][mi].v));
+      if (t == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(xa[t & 1][mi].v));
-        if (t == 0) {
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(zb[ni].v));
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[t & 1][mi].v, zb[ni].v, acc[t][mi][ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(zb[ni].v));
       }
-    }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[t % 3][mi].v, zb[ni].v, acc[t][mi][ni], 0, 0, 0);
+    };
+    static_for<0, G::TAPS_W>(tap_step);
     __builtin_amdgcn_s_waitcnt(vmcnt_only((G::NST - 2) * G::DPS) & lgkmcnt_only(0));
     __builtin_amdgcn_s_barrier();
-    rb = rb + 1 == G::NST ? 0 : rb + 1;
-    wb = wb + 1 == G::NST ? 0 : wb + 1;
+  };
+  for (int seg = s_begin;;) {
+    segment(std::integral_constant<int, 0>{});
+    if (++seg >= s_end) break;
+    segment(std::integral_constant<int, 1>{});
+    if (++seg >= s_end) break;
+    segment(std::integral_constant<int, 2>{});
+    if (++seg >= s_end) break;
+    if constexpr (G::NST == 4) {
+      segment(std::integral_constant<int, 3>{});
+      if (++seg >= s_end) break;
+    }
   }
   __builtin_amdgcn_s_waitcnt(vmcnt_only(0));                          // the re-fetched tail segments land before the block's LDS is released
 
@@ -270,7 +317,6 @@ int launch_alltaps(WgradAArgs& a, hipStream_t st) {
   a.tiles_n = (a.Cz + CO_T - 1) / CO_T;
   const long tiles = (long)tiles_m * a.tiles_n;
   a.segs_x = (a.W + 31) / 32;
-  a.col_order = getenv("SHDR_ALLTAPS_ROW_ORDER") == nullptr;
   a.nsegs = a.N * a.H * a.segs_x;
   // segment slices: ONE round of the chip's block slots (CUs x occupancy; wgrad_f16.hip has the measurements), at least 32
   // segments (1024 pixels) per block so that the KK^2 x CI_T x CO_T atomics of a block stay cheap
