@@ -109,7 +109,13 @@ typedef struct shdr_conv2d_desc {
    * convolution's input, i.e. of the up-sampled image.  On the fused Winograd plan the up-sampled tensor never exists in HBM;
    * every other plan materialises it in the workspace (shdr_conv2d_workspace_bytes_f32 accounts for it). */
   int32_t prologue;
+  /* Kind of the optional 2x2 / stride-2 pooled second output y_pool of the forward calls that take a prepared filter:
+   * SHDR_POOL_MAX (MaxPool2D(2): hallucination_net.py:47-49, vgg16.py:72-83) or SHDR_POOL_AVG (AveragePooling2D(2):
+   * dequantization_net.py:9-10, the encoder of both U-Nets pools each level's output for the next one).  Written by the conv
+   * kernel's own epilogue on the fused Winograd (max), split-operand and narrow split-operand plans, by a pooling launch otherwise. */
+  int32_t pool;
 } shdr_conv2d_desc;
+enum { SHDR_POOL_MAX = 0, SHDR_POOL_AVG = 1 };
 enum { SHDR_PROLOGUE_NONE = 0, SHDR_PROLOGUE_BILINEAR2X = 1,
        /* split-operand kernel only (shdr_conv2d_fwd_x3_f32): x1 is scaled in the kernel by the power of two that brings max |x1| -- written
         * into the prepared filter's header by shdr_conv2d_x3_input_absmax_f32 -- into the fp16 range; for inputs far below it (gradients) */
@@ -139,8 +145,9 @@ int shdr_conv2d_filter_is_plain_f32(const shdr_conv2d_desc* d, int has_residual)
 int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has_residual, const float* w, float* prepared, void* stream);
 /* caller-provided scratch of shdr_conv2d_fwd_prepared_f32 (0 for every plan but WINOGRAD_PLANES) */
 int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_residual);
-/* y = act2(affine(act1(conv + bias)) + residual) with the planned kernel; y_pool (optional) = MaxPool2D(2)(y) -- written by the
- * same launch on the fused Winograd path (where y itself may then be NULL), by a pooling launch otherwise
+/* y = act2(affine(act1(conv + bias)) + residual) with the planned kernel; y_pool (optional) = MaxPool2D(2)(y) or, with
+ * desc.pool = SHDR_POOL_AVG, AveragePooling2D(2)(y) -- written by the same launch on the fused Winograd (max only) and
+ * split-operand plans (where y itself may then be NULL on the wide ones), by a pooling launch otherwise
  * (hallucination_net.py:47-49,63-66: the conv + max-pool pairs of the encoder). */
 int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
                                  const float* bias, const float* scale, const float* shift, const float* residual, float* y,
@@ -400,7 +407,7 @@ int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d);
 int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d);
 int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                            const float* scale, const float* shift, const float* residual, float* y, void* stream);
+                            const float* scale, const float* shift, const float* residual, float* y, float* y_pool, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

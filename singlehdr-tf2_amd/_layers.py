@@ -137,6 +137,10 @@ class Conv2D(Layer):
     def call(self, x, **kw):
         return K.conv2d(x, self.kernel, self.bias, stride=self.strides, **kw)
 
+    def call_avgpool2(self, x, **kw):
+        """(y, AveragePooling2D(2)(y)) of this layer: the pooled tensor from the conv kernel's epilogue where the plan allows it"""
+        return K.conv2d_avgpool2(x, self.kernel, self.bias, **kw)
+
     def call_up2(self, x, **kw):
         """this layer applied to tf.image.resize(x, 2x, BILINEAR): one fused kernel where the library's plan allows it"""
         return K.conv2d_up2(x, self.kernel, self.bias, **kw)

@@ -29,7 +29,7 @@ class ConvDesc(ctypes.Structure):
                 ("w_batch_stride", ctypes.c_int64),
                 ("y_pix_stride", ctypes.c_int32), ("y_off_h", ctypes.c_int32), ("y_off_w", ctypes.c_int32),
                 ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32),
-                ("prologue", ctypes.c_int32)]
+                ("prologue", ctypes.c_int32), ("pool", ctypes.c_int32)]
 
 
 OP_CONV2D_FWD, OP_CONV2D_DGRAD, OP_CONV2D_WGRAD_WINOGRAD, OP_BATCHNORM, OP_ACT_BWD_BIAS = 0, 1, 2, 3, 4     # shdr_workspace_bytes(op, ...)
@@ -58,7 +58,7 @@ SIGNATURES = {
     "shdr_conv2d_x3n_ok_f32": (c_int, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_x3n_filter_elems_f32": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_x3n_prepare_filter_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_ptr, c_ptr]),
-    "shdr_conv2d_fwd_x3n_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_conv2d_fwd_x3n_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 10),
     "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),

@@ -28,6 +28,7 @@ WINOGRAD = True   # False: ask the library for the plain (non-Winograd) kernels 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 ALGO_AUTO, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_REG = 0, 1, 2, 3
 PROLOGUE_NONE, PROLOGUE_BILINEAR2X = 0, 1      # shdr_conv2d_desc.prologue
+POOL_MAX, POOL_AVG = 0, 1                      # shdr_conv2d_desc.pool
 ALGO_MFMA_F16, ALGO_MFMA_BF16, ALGO_AUTO_F16, ALGO_AUTO_BF16 = 4, 5, 6, 7
 ALGO_AUTO_EXACT = 8    # AUTO without the split-operand fp16 kernel (plan "x3"): every product an fp32 FMA / fp32 MFMA
 EXACT_FP32 = False     # True: ask the library for ALGO_AUTO_EXACT wherever this module would ask for ALGO_AUTO
@@ -171,7 +172,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     """One convolution through the C ABI.  The kernel family (one-kernel Winograd, three-kernel Winograd, register-A / LDS-DMA
     implicit GEMM, direct) is chosen BELOW the ABI (shdr_conv2d_plan_f32, csrc/conv_plan.hip); this wrapper only checks shapes,
     caches the prepared filter of persistent variables per version and provides memory.  pool: None, True (also return
-    MaxPool2D(2)(y)) or "only"."""
+    MaxPool2D(2)(y)), "only" (the pooled tensor alone) or "avg" (also return AveragePooling2D(2)(y))."""
     lib = _lib.load()
     x = _chk(_d(x), "x")
     w_var = w                          # the variable itself: its version / leaf status key the prepared-filter cache
@@ -205,6 +206,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     d.algo = _auto(algo)
     d.w_batch_stride = int(w_batch_stride)
     d.prologue = int(prologue)
+    d.pool = POOL_AVG if pool == "avg" else POOL_MAX
     res_cs = 0
     if residual is not None:
         residual = _chk(_d(residual), "residual")
@@ -1300,6 +1302,17 @@ def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
         return maxpool2(y)
     ya, yb = fork(y)                   # the skip connection and the pooling both consume y
     return ya, maxpool2(yb)
+
+
+def conv2d_avgpool2(x, w, bias=None, act1=ACT_NONE, x2=None):
+    """(y, AveragePooling2D(2)(y)) with y = act1(conv(concat[x, x2], w) + bias): the encoder levels of the two U-Nets
+    (dequantization_net.py:9-13 pools each level's output for the next one and keeps it as the skip connection).  Without a tape
+    the pooled tensor comes out of the conv kernel's own epilogue on the split-operand plans -- decided below the C ABI."""
+    if not _is_h(x) and not _needs_grad(x, w, bias, x2) and PRECISION in ("fp32", "fp16") and WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+        return _conv2d_raw(x, w, bias, 1, x2, 1.0, act1, None, None, None, ACT_NONE, ALGO_AUTO, None, None, None, None, 0, "avg")
+    y = conv2d(x, w, bias, x2=x2, act1=act1)
+    ya, yb = fork(y)                   # the skip connection and the pooling both consume y
+    return ya, avgpool2(yb)
 
 
 def conv2d_winograd(x, u, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):

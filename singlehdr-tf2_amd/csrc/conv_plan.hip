@@ -200,8 +200,16 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
                                             const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
                                             void* workspace, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_fwd_prepared: null desc / x1 / prepared filter / output");
-  SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared: the fused 2x2 max-pool needs even Ho, Wo");
+  SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared: the fused 2x2 pooling needs even Ho, Wo");
+  SHDR_REQUIRE(d->pool == SHDR_POOL_MAX || d->pool == SHDR_POOL_AVG, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown pool kind");
   const int plan = plan_of(d, residual != nullptr);
+  const bool avg = y_pool && d->pool == SHDR_POOL_AVG;
+  if (avg && (plan == SHDR_PLAN_WINOGRAD_FUSED || (d->prologue == SHDR_PROLOGUE_BILINEAR2X && plan != SHDR_PLAN_X3))) {
+    // the Winograd kernel's epilogue pools by maximum only: convolution, then the pooling launch
+    SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: this plan writes y before it pools");
+    if (int rcw = shdr_conv2d_fwd_prepared_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, nullptr, workspace, stream)) return rcw;
+    return shdr_avgpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, d->Cout, stream);
+  }
   if (d->prologue != SHDR_PROLOGUE_NONE) {
     SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_BILINEAR2X, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown prologue");
     SHDR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->C2 == 0 && x2 == nullptr, SHDR_E_SHAPE,
@@ -230,7 +238,9 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd and split-operand paths");
   int rc;
   if (plan == SHDR_PLAN_X3N) {
-    rc = shdr_conv2d_fwd_x3n_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, stream);
+    const bool in_kernel = y_pool && d->y_pix_stride <= 1 && (d->cout_valid == 0 || d->cout_valid == d->Cout);
+    rc = shdr_conv2d_fwd_x3n_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, in_kernel ? y_pool : nullptr, stream);
+    if (rc || in_kernel) return rc;
   } else if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
     SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
     const int Cin = d->C1;
@@ -254,7 +264,7 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
   if (y_pool) {
     SHDR_REQUIRE(d->y_pix_stride <= 1, SHDR_E_SHAPE, "conv2d_fwd_prepared: no pooled output with a strided y");
     const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
-    return shdr_maxpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream);
+    return avg ? shdr_avgpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream) : shdr_maxpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream);
   }
   return SHDR_OK;
 }
@@ -297,7 +307,7 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
       if (int rc = shdr_conv2d_x3n_prepare_filter_f32(&c, wt, u, stream)) return rc;
       if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;       // header slot 2, as the wide kernel
       c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
-      return shdr_conv2d_fwd_x3n_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, nullptr, dx, stream);
+      return shdr_conv2d_fwd_x3n_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, nullptr, dx, nullptr, stream);
     }
     if (g.x3) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);

@@ -69,6 +69,7 @@ struct X3Args {
   int Hin, Win;            // input tensor [N,Hin,Win,C]; tap (kh, kw) of output (oh, ow) reads input (in_s (oh + kh) + bh, in_s (ow + kw) + bw)
   int in_s, bh, bw;        // stride-1 3x3 SAME: in_s = 1, bh = bw = -1
   int final;               // 0: store the raw partial sum (another phase follows), 1: the epilogue
+  int pool_avg;            // yp = AveragePooling2D(2)(y) instead of MaxPool2D(2)(y)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -362,8 +363,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         f32x4 m;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          m[e] = fmaxf(v[0][e], v[1][e]);
-          m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
+          if (a.pool_avg) {                                    // (top-left + top-right) + (bottom-left + bottom-right), as pool.hip adds them
+            const float t = v[0][e] + __shfl_xor(v[0][e], 1, 64), b = v[1][e] + __shfl_xor(v[1][e], 1, 64);
+            m[e] = 0.25f * (t + b);
+          } else {
+            m[e] = fmaxf(v[0][e], v[1][e]);
+            m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
+          }
         }
         if (!(pc & 1) && ow < a.W)                               // lanes fi and fi ^ 1 hold columns pc and pc ^ 1
           *reinterpret_cast<f32x4*>(a.yp + ((size_t)(img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + n0 + cl) = m;
@@ -557,6 +563,7 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
   X3Args a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1;
   a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = y_pool;
+  a.pool_avg = d->pool == SHDR_POOL_AVG;
   a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C1 = d->C1; a.C2 = d->C2; a.Cout = d->Cout;
   a.Hin = d->H; a.Win = d->W;
   a.Hl = d->H / 2; a.Wl = d->W / 2;

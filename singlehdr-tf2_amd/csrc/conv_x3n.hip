@@ -34,6 +34,8 @@ struct X3nArgs {
   const float* shift;
   const float* res;        // residual [N,H,W,res_cs] (or null)
   float* y;                // [N,H,W,cout_valid]
+  float* yp;               // [N,H/2,W/2,COUT] = 2x2 pooled y (or null): needs even H, W and cout_valid == COUT
+  int pool_avg;            // AveragePooling2D(2) instead of MaxPool2D(2)
   int N, H, W, C1, tiles_x, tiles_y, ntiles, act1, act2, cout_valid, res_cs;
   int rs;                  // range scale: multiply the input by the power of two that brings hdr[2] = max |x| to [2^10, 2^11) (output gradients)
 };
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
           // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
           *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
+          acc[mi][ni] = v;                                            // kept for the pooled output below
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -265,6 +268,32 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
               if (a.res) t += a.res[pix * a.res_cs + co + e];
               a.y[pix * a.cout_valid + co + e] = shdr::act_apply(t, a.act2);
             }
+        }
+      }
+    }
+    // ---- optional second output: the 2 x 2 window is rows (2 mp, 2 mp + 1) of this lane and of lane fi ^ 1 (H, W even: a window is
+    //      inside the image or outside as a whole); sums in pool.hip's order, (top-left + top-right) + (bottom-left + bottom-right)
+    if (a.yp) {
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+        const int oh = oh0 + wave * MT + 2 * mp, ow = ow0 + fi;
+        if (oh >= a.H) continue;                                      // wave-uniform
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          f32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t0 = acc[2 * mp][ni][e], b0 = acc[2 * mp + 1][ni][e];
+            if (a.pool_avg) {
+              const float t = t0 + __shfl_xor(t0, 1, 64), b = b0 + __shfl_xor(b0, 1, 64);
+              m[e] = 0.25f * (t + b);
+            } else {
+              const float mx = fmaxf(t0, b0);
+              m[e] = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            }
+          }
+          if (!(fi & 1) && ow < a.W)
+            *reinterpret_cast<f32x4*>(a.yp + (((size_t)img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * G::COUT + ni * 16 + 4 * fg) = m;
         }
       }
     }
@@ -394,8 +423,10 @@ extern "C" int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, con
 }
 
 extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                       const float* scale, const float* shift, const float* residual, float* y, void* stream) {
+                                       const float* scale, const float* shift, const float* residual, float* y, float* y_pool, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && y, SHDR_E_NULL, "conv2d_x3n: null desc/x1/filter/y");
+  SHDR_REQUIRE(!y_pool || (d->H % 2 == 0 && d->W % 2 == 0 && shdr::aligned16(y_pool) && (d->cout_valid == 0 || d->cout_valid == d->Cout)),
+               SHDR_E_SHAPE, "conv2d_x3n: the pooled output needs even H, W and every filter column stored");
   SHDR_REQUIRE(shdr_conv2d_x3n_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3n: layer shape not taken by this kernel");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3n: x2 must be given iff C2 > 0");
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3n: scale and shift come together");
@@ -407,6 +438,7 @@ extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x
   a.hdr = prepared;
   a.wp = reinterpret_cast<const _Float16*>(prepared + XN_HEADER_FLOATS);
   a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.yp = y_pool; a.pool_avg = d->pool == SHDR_POOL_AVG;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1;
   a.tiles_x = (d->W + 15) / 16;
   a.tiles_y = (d->H + 15) / 16;

@@ -29,6 +29,12 @@ class down(Layer):
         x = self.conv1(x, act1=K.ACT_LRELU)
         return self.conv2(x, act1=K.ACT_LRELU)
 
+    def call_pooled(self, xp):
+        """the block on an input that is pooled already (the previous level's conv wrote it from its epilogue); returns this
+        level's output and its own AveragePooling2D(2) for the next level"""
+        x = self.conv1(xp, act1=K.ACT_LRELU)
+        return self.conv2.call_avgpool2(x, act1=K.ACT_LRELU)
+
 
 class up(Layer):
     """bilinear 2x -> conv+lrelu -> conv(concat[x, skip])+lrelu (dequantization_net.py:17-29).
@@ -69,11 +75,13 @@ class _unet(Layer):
             x = self.conv1.call_padded(input_images, cin_pad=cin, act1=K.ACT_LRELU)
         else:
             x = self.conv1(input_images, act1=K.ACT_LRELU)
-        s1, t1 = K.fork(self.conv2(x, act1=K.ACT_LRELU))      # each encoder output feeds the next level and its skip connection
-        s2, t2 = K.fork(self.d2(t1))
-        s3, t3 = K.fork(self.d3(t2))
-        s4, t4 = K.fork(self.d4(t3))
-        x = self.enc(t4)
+        # each encoder output feeds its skip connection and, average-pooled, the next level (dequantization_net.py:9-10): the
+        # producing conv writes both tensors (K.conv2d_avgpool2; with a tape: conv, fork, pooling launch)
+        s1, p1 = self.conv2.call_avgpool2(x, act1=K.ACT_LRELU)
+        s2, p2 = self.d2.call_pooled(p1)
+        s3, p3 = self.d3.call_pooled(p2)
+        s4, p4 = self.d4.call_pooled(p3)
+        x = self.enc.conv2(self.enc.conv1(p4, act1=K.ACT_LRELU), act1=K.ACT_LRELU)
         x = self.u4(x, s4)
         x = self.u3(x, s3)
         x = self.u2(x, s2)

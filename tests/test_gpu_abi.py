@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):            # the mirror of INTEGRATION.md sect
                [("x2_scale", ctypes.c_float)] + \
                [(n, ctypes.c_int32) for n in ("act1", "act2", "res_cstride", "y_cstride", "algo", "cout_valid")] + \
                [("w_batch_stride", ctypes.c_int64)] + \
-               [(n, ctypes.c_int32) for n in ("y_pix_stride", "y_off_h", "y_off_w", "y_H", "y_W", "prologue")]
+               [(n, ctypes.c_int32) for n in ("y_pix_stride", "y_off_h", "y_off_w", "y_H", "y_W", "prologue", "pool")]
 
 
 @pytest.fixture(scope="module")

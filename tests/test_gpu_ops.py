@@ -424,6 +424,34 @@ def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     assert torch.equal(K.conv2d(dev(x), dev(wt), None, act1=K.ACT_RELU), y)
 
 
+AVGPOOL_CASES = [  # name, n, h, w, cin, cout, k, expected plan
+    ("x3n_7x7_16_16", 2, 32, 48, 16, 16, 7, "x3n"), ("x3n_5x5_32_32_ragged_tiles", 1, 38, 26, 32, 32, 5, "x3n"),
+    ("x3n_3x3_16_32", 1, 16, 16, 16, 32, 3, "x3n"), ("x3_3x3_64_64", 2, 32, 48, 64, 64, 3, "x3"),
+    ("x3_3x3_128_128_ragged_tiles", 1, 22, 38, 128, 128, 3, "x3"), ("fallback_3x3_48_48", 1, 12, 20, 48, 48, 3, None),
+]
+
+
+@pytest.mark.parametrize("case", AVGPOOL_CASES, ids=[c[0] for c in AVGPOOL_CASES])
+def test_conv2d_avgpool2_pair(shdr, case, monkeypatch):
+    """conv + AveragePooling2D(2) pairs of the U-Net encoders (dequantization_net.py:9-13): the split-operand kernels write the
+    pooled tensor from their own epilogue (desc.pool = SHDR_POOL_AVG), every other plan pools in a second launch below the ABI.
+    y is the plain call's y bit for bit, and the pooled tensor is avgpool2(y) bit for bit (same order of additions)."""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    name, n, h, w, cin, cout, k, plan = case
+    K = shdr._ops
+    rng = np.random.default_rng(len(name) + h)
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+    b = f32(rng.normal(size=cout) * 0.1)
+    if plan is not None:
+        assert K.conv2d_plan((n, h, w, cin), wt.shape) == plan
+    y, yp = K.conv2d_avgpool2(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU)
+    assert rel_err(host(y), oracle_conv(x, wt, b, act1=2)) <= TOL
+    assert torch.equal(y, K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU))
+    assert tuple(yp.shape) == (n, h // 2, w // 2, cout) and torch.equal(yp, K.avgpool2(y))
+    np.testing.assert_allclose(host(yp), ops.avg_pool2(host(y).astype(np.float64)), rtol=1e-6, atol=1e-7)
+
+
 X3N_CASES = [  # name, n, h, w, c1, c2, cout (filter width), cout_valid, k, act1, residual
     ("deq_conv1_7x7_4_16", 1, 40, 52, 4, 0, 16, 16, 7, 2, False), ("deq_conv2_7x7_16_16", 2, 33, 47, 16, 0, 16, 16, 7, 2, False),
     ("deq_d2_5x5_16_32", 1, 24, 40, 16, 0, 32, 32, 5, 2, False), ("deq_u1_3x3_32_16", 1, 50, 34, 32, 0, 16, 16, 3, 2, False),
