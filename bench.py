@@ -395,6 +395,24 @@ def main():
                                 "%dx%d %d+0->%d k3 s1 +pool" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3]), False))
                 return out
 
+            orig_ap = K.conv2d_avgpool2
+
+            def timed_conv_avgpool(x, w, bias=None, act1=0, x2=None):
+                # conv + AveragePooling2D(2) pairs of the U-Net encoders: the pooled tensor comes out of the split-operand kernels'
+                # own epilogue (timed here as that launch), otherwise conv2d() [recorded by timed_conv] + avgpool2
+                c2 = 0 if x2 is None else x2.shape[3]
+                plan = K.conv2d_plan(tuple(x.shape), tuple(w.shape), c2=c2) if K.WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 else None
+                if plan not in ("x3", "x3n"):
+                    y = timed_conv(x, w, bias, x2=x2, act1=act1)
+                    return y, K.avgpool2(y)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig_ap(x, w, bias, act1, x2)
+                e1.record()
+                records.append(("conv_x3_kernel" if plan == "x3" else "conv_x3n_kernel", conv_flops(x, w, 1, None), e0, e1,
+                                "%dx%d %d+%d->%d k%d s1 +avgpool" % (x.shape[1], x.shape[2], x.shape[3], c2, w.shape[3], w.shape[0]), False))
+                return out
+
             orig_up = K.conv2d_up2
 
             def timed_conv_up2(x, w, bias=None, **kw):
@@ -416,13 +434,13 @@ def main():
             reps = 3
             eager(ldr)           # the caching allocator's pool of THIS stream (the timed leg may have run on side streams)
             torch.cuda.synchronize()
-            K.conv2d, K.conv2d_maxpool2, K.conv2d_up2 = timed_conv, timed_conv_pool, timed_conv_up2
+            K.conv2d, K.conv2d_maxpool2, K.conv2d_up2, K.conv2d_avgpool2 = timed_conv, timed_conv_pool, timed_conv_up2, timed_conv_avgpool
             try:
                 for _ in range(reps):
                     eager(ldr)
                 torch.cuda.synchronize()
             finally:
-                K.conv2d, K.conv2d_maxpool2, K.conv2d_up2 = orig, orig_cp, orig_up
+                K.conv2d, K.conv2d_maxpool2, K.conv2d_up2, K.conv2d_avgpool2 = orig, orig_cp, orig_up, orig_ap
             # one entry per conv call of ONE pass, timed as the median over the `reps` passes (a host-side hiccup --
             # e.g. the runtime growing its signal pool inside hipEventRecord -- shows up as GPU idle time between
             # the two events of whichever call it hits, in one pass only)
