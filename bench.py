@@ -257,7 +257,7 @@ def main():
                    "per_gpu_batch": args.batch, "hip_streams_per_gpu": args.streams,
                    "parallelism": "batch-sharded x%d, no collective" % n_gpus},
     }
-    if rank == 0 and n_gpus == 1 and not args.exact_fp32:
+    if rank == 0 and n_gpus == 1 and not args.exact_fp32 and not args.no_roofline:      # (--no-roofline = the lean runs under the profiler)
         # the same leg with every layer on the exact-fp32 kernels (fp32 MFMA / FMA products only), and how far the two results are apart
         K.EXACT_FP32 = True
         try:
