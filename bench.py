@@ -697,7 +697,7 @@ def main():
                          "images_per_s": round(b * world * args.finetune_steps / fdt, 3),
                          "tflops_algorithmic_per_gpu": round(gflop_img * b * args.finetune_steps / fdt / 1e3, 2),
                          "loss_sum": round(floss, 3), "skipped_steps": fstep.skipped_steps}
-            if prec == "fp16" and rank == 0 and not args.no_roofline:
+            if prec == "fp16" and rank == 0 and world == 1 and not args.no_roofline:      # the instrumented step all-reduces: N = 1 only
                 try:
                     leg[prec]["roofline"] = fp16_roofline(K, fstep, f_ldr, f_hdr)
                 except Exception as exc:
