@@ -167,3 +167,16 @@ def test_documented_ctypes_mirror_matches_the_header():
     ns = {"ctypes": ctypes}
     exec(snippet, ns)
     assert [(n, t) for n, t in ns["ConvDesc"]._fields_] == list(lib.ConvDesc._fields_)
+
+
+def test_bench_rank0_only_legs_hold_no_collective():
+    """bench.py runs some legs on rank 0 only; a leg that steps a DP model there all-reduces alone and hangs the N > 1 runs
+    (the instrumented fp16 fine-tuning step did): such legs must be restricted to world == 1."""
+    src = open(os.path.join(ROOT, "bench.py")).read().splitlines()
+    for i, line in enumerate(src):
+        if "= fp16_roofline(K, fstep" in line:
+            cond = " ".join(src[max(0, i - 3):i])
+            assert "world == 1" in cond, "bench.py:%d steps the DP fine-tuning model on rank 0 only" % (i + 1)
+            break
+    else:
+        raise AssertionError("fp16 roofline leg not found")
