@@ -383,7 +383,9 @@ extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
   if (d->pad_t != (d->KH - 1) / 2 || d->pad_l != (d->KW - 1) / 2 || d->Ho != d->H || d->Wo != d->W) return 0;
   // (desc.prologue plays no part: the plan of a layer must not depend on it -- shdr_conv2d_fwd_prepared_f32 materialises a prologue this
   //  kernel does not fuse and re-enters with the same prepared filter)
-  if (!(d->Cout == 16 || d->Cout == 32) || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
+  // Cout 64: the 3x3 image layers (3 -> 4 channels in, hal conv1_1 / VGG conv1_1: K = 36, an HBM-write-bound layer)
+  const bool image64 = d->Cout == 64 && d->KH == 3 && d->C2 == 0 && d->C1 <= 8 && getenv("SHDR_NO_X3N_IMAGE64") == nullptr;
+  if (!(d->Cout == 16 || d->Cout == 32 || image64) || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv > d->Cout || (d->y_cstride != 0 && d->y_cstride != cv)) return 0;
   const bool one = d->C2 == 0 && d->C1 % 4 == 0 && d->C1 >= 4 && d->C1 <= 32, two = d->C1 == 16 && d->C2 == 16;
@@ -399,7 +401,7 @@ extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
 }
 
 extern "C" int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d) {
-  if (!d || d->KH <= 0 || !(d->Cout == 16 || d->Cout == 32)) return -1;
+  if (!d || d->KH <= 0 || !(d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return -1;
   const int ct = ct_of(d);
   const int64_t ns = (d->KH * d->KW * ct + 31) / 32;
   return XN_HEADER_FLOATS + ns * d->Cout * 32;               // header + two fp16 images, in floats
@@ -448,6 +450,7 @@ extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x
   a.cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   a.res_cs = d->res_cstride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->Cout == 64) return launch_x3n<3, 8, 4, false>(a, st);
   if (d->Cout == 16) {
     if (d->KH == 3) return dispatch_ct<3, 1>(a, d, st);
     if (d->KH == 5) return dispatch_ct<5, 1>(a, d, st);

@@ -457,6 +457,7 @@ X3N_CASES = [  # name, n, h, w, c1, c2, cout (filter width), cout_valid, k, act1
     ("deq_d2_5x5_16_32", 1, 24, 40, 16, 0, 32, 32, 5, 2, False), ("deq_u1_3x3_32_16", 1, 50, 34, 32, 0, 16, 16, 3, 2, False),
     ("deq_u1_concat_16_16_16", 2, 21, 35, 16, 16, 16, 16, 3, 2, False), ("deq_out_3x3_16_3_tanh_residual", 1, 36, 36, 16, 0, 16, 3, 3, 3, True),
     ("ref_conv1_7x7_12_16", 1, 20, 28, 12, 0, 16, 16, 7, 2, False), ("d3_3x3_32_32", 1, 18, 18, 32, 0, 32, 32, 3, 1, True),
+    ("hal_conv1_1_3x3_4_64_relu", 2, 40, 52, 4, 0, 64, 64, 3, 1, False),       # the 3 -> 4 channel image layers: 64 couts (NT = 4)
 ]
 
 
