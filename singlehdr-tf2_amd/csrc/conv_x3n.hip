@@ -174,12 +174,24 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
   }
   const float inv_s = a.hdr[1] * ixs;
 
+  // Workgroup barriers of the tile loop order LDS traffic only: __syncthreads() also fences global memory (s_waitcnt vmcnt(0)), i.e.
+  // every wave would sit out the write latency of the previous tile's output stores at the top of each tile (PMC on the 3x3 4 -> 64
+  // image layer: 63 % of the wave cycles in s_waitcnt with two blocks per CU).  The stores stay in flight across the raw barrier;
+  // the patch registers are waited for by the compiler's own counted vmcnt (loads and stores retire in issue order).
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // The bias is the same for every tile of the persistent block: loaded once.  Inside the epilogue each of its loads was followed by
+  // "s_waitcnt vmcnt(0)", which also drained the output store issued just before it -- sixteen serialised store round trips per tile.
+  f32x4 bias_r[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+    bias_r[ni] = (a.bias && a.cout_valid == G::COUT) ? *reinterpret_cast<const f32x4*>(a.bias + ni * 16 + 4 * fg) : (f32x4){0.f, 0.f, 0.f, 0.f};
   int tile = blockIdx.x;
   if (tile < a.ntiles) load_patch(tile);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the filter (LDS-DMA) have landed
   for (; tile < a.ntiles; tile += gridDim.x) {
-    __syncthreads();                                           // every wave is done with the previous tile's patch (and the filter has landed)
+    lds_barrier();                                             // every wave is done with the previous tile's patch (first tile: the filter is complete)
     store_patch();
-    __syncthreads();
+    lds_barrier();
     const int next = tile + gridDim.x;
     if (next < a.ntiles) load_patch(next);                     // lands under this tile's MFMAs
     f32x4 acc[MT][NT];
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
         f32x4 v = acc[mi][ni] * inv_s;
         // y = act2(affine(act1(acc + bias)) + residual)
         if (a.cout_valid == G::COUT) {
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+          v += bias_r[ni];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
           if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + co) + *reinterpret_cast<const f32x4*>(a.shift + co);
