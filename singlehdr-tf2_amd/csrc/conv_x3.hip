@@ -333,6 +333,36 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
   const float inv_s = a.hdr[1] * ixs;
   const int ow = ow0 + pc;                                     // the lane's tile column (pcol permutation)
+  // bias / scale / shift of the lane's four cout quads are loaded ONCE, in front of the store loop: a load inside it is followed by
+  // "s_waitcnt vmcnt(0)", which also sits out the round trip of the output store issued just before it -- the stores of a block went
+  // out one at a time
+  // (the offsets pass through an opaque asm so that the loads are not hoisted above the tap loop, where their registers would be live
+  //  for the whole kernel)
+  int ep0 = n0;
+  asm volatile("" : "+s"(ep0));
+  f32x4 bias_r[NT], scale_r[NT], shift_r[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int cl = ni * 16 + 4 * fg;
+    bias_r[ni] = (a.bias && a.final) ? *reinterpret_cast<const f32x4*>(a.bias + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    scale_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.scale + ep0 + cl) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    shift_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.shift + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // the partial sums of the earlier phases of a stride-2 layer (yin), batched in front of the stores for the same reason
+  f32x4 yin_r[MT / 2][NT][2];
+  if (a.yin) {
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int oh = oh0 + wave * MT + 2 * mp + r;
+          yin_r[mp][ni][r] = (oh < a.H && ow < a.W)
+                                 ? *reinterpret_cast<const f32x4*>(a.yin + ((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + ep0 + ni * 16 + 4 * fg)
+                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+  }
 #pragma unroll
   for (int mp = 0; mp < MT / 2; ++mp) {
     const int oh = oh0 + wave * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
@@ -345,15 +375,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       for (int r = 0; r < 2; ++r) {
         v[r] = acc[2 * mp + r][ni] * inv_s;
         const bool inside = oh + r < a.H && ow < a.W;
-        if (a.yin && inside) v[r] += *reinterpret_cast<const f32x4*>(a.yin + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl);
+        if (a.yin) v[r] += yin_r[mp][ni][r];
         if (!a.final) {
           if (inside) *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
           continue;
         }
-        if (a.bias) v[r] += *reinterpret_cast<const f32x4*>(a.bias + n0 + cl);
+        v[r] += bias_r[ni];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act1);
-        if (a.scale) v[r] = v[r] * *reinterpret_cast<const f32x4*>(a.scale + n0 + cl) + *reinterpret_cast<const f32x4*>(a.shift + n0 + cl);
+        if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
         if (a.y && oh + r < a.H && ow < a.W)
