@@ -134,11 +134,23 @@ __global__ __launch_bounds__(256) void conv_f16_patch_kernel(const PatchArgs a) 
     b_rd[ni] = row * 32 + 8 * (fg ^ pswz(row));
   }
 
+  // the bias is the same for every tile of the persistent block: loaded once (inside the epilogue each load is followed by
+  // "s_waitcnt vmcnt(0)", which sat out the round trip of the output store before it and of the next tile's patch DMA)
+  f32x4 bias_r[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+    bias_r[ni] = (a.bias && !a.y32) ? *reinterpret_cast<const f32x4*>(a.bias + ni * 16 + 4 * fg) : (f32x4){0.f, 0.f, 0.f, 0.f};
   int tile = blockIdx.x;
   if (tile < a.ntiles) dma_patch(tile, 0);
   int buf = 0;
+  // The barrier of the tile loop waits for this wave's patch DMA only: the DMA of patch(tile) is OLDER than the output stores of the
+  // previous tile (vector-memory operations retire in issue order), so "vmcnt(stores issued since)" lets those stores stay in flight;
+  // __syncthreads() is a full fence (vmcnt(0)) and sat out their round trip once per tile.
+  int stores_since = -1;                                        // -1: unknown -> drain
   for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
-    __syncthreads();                                           // patch(tile) (and the filter) landed; everyone is done with buf ^ 1
+    if (stores_since == MT * NT) __builtin_amdgcn_s_waitcnt(0x0F70 | ((MT * NT) & 15) | (((MT * NT) >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // patch(tile) (and the filter) landed; everyone is done with buf ^ 1
     const int next = tile + gridDim.x;
     if (next < a.ntiles) dma_patch(next, buf ^ 1);
     const _Float16* P = patch + buf * G::PATCH_HALVES;
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(256) void conv_f16_patch_kernel(const PatchArgs a) 
     const int ty = pm % a.tiles_y;
     const int img = pm / a.tiles_y;
     const int oh0 = ty * 16, ow0 = tx * 16;
+    stores_since = (!a.y32 && oh0 + wave * MT + MT <= a.H) ? MT * NT : -1;      // one 8-byte store per (row, cout tile) of this wave
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int oh = oh0 + wave * MT + mi, ow = ow0 + fi;
@@ -201,10 +214,7 @@ __global__ __launch_bounds__(256) void conv_f16_patch_kernel(const PatchArgs a) 
           for (int e = 0; e < 4; ++e)
             if (co + e < a.cout_valid) a.y32[pix * a.cout_valid + co + e] = shdr::act_apply(v[e] + (a.bias ? a.bias[co + e] : 0.f), a.act1);
         } else {
-          if (a.bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-          }
+          v += bias_r[ni];
           f16x4 h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) h[e] = (_Float16)shdr::act_apply(v[e], a.act1);
