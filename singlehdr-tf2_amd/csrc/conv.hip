@@ -152,25 +152,26 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
   __syncthreads();
   constexpr int QR = BN / 4;                           // float4 per tile row
   constexpr int TOTAL = BM * QR;
+  static_assert(256 % QR == 0, "a thread keeps its cout quad over the store loop");
+  // 256 % QR == 0: the thread's cout quad q is the same in every iteration, so bias / scale / shift are loaded ONCE in front of the
+  // store loop (a load inside it is followed by s_waitcnt vmcnt(0), which also sits out the stores issued before it)
+  const int q = tid % QR, co = n0 + 4 * q;
+  const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 s4 = a.scale ? *reinterpret_cast<const float4*>(a.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 t4 = a.scale ? *reinterpret_cast<const float4*>(a.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
   for (int e = tid; e < TOTAL; e += 256) {
-    const int r = e / QR, q = e - r * QR;
+    const int r = e / QR;
     const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
     if (oh >= a.Ho || ow >= a.Wo) continue;
-    const int co = n0 + 4 * q;
     const size_t pix = ((size_t)img * a.YH + oh * a.ys + a.yoh) * a.YW + ow * a.ys + a.yow;
     float4 v = *reinterpret_cast<const float4*>(stage + r * RS + 4 * q);
-    if (a.bias) {
-      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-    }
+    if (a.bias) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
     if (a.act1 != SHDR_ACT_NONE) {
       v.x = shdr::act_apply(v.x, a.act1); v.y = shdr::act_apply(v.y, a.act1);
       v.z = shdr::act_apply(v.z, a.act1); v.w = shdr::act_apply(v.w, a.act1);
     }
     if (a.scale) {
-      const float4 s4 = *reinterpret_cast<const float4*>(a.scale + co);
-      const float4 t4 = *reinterpret_cast<const float4*>(a.shift + co);
       v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
     }
     if (a.res) {
