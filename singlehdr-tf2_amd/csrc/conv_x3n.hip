@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
     }
   }
   f32x4 pr[G::PJ];
+  // the 7x7 image layers (4 -> 16: four stores per tile and a long tap loop) measured 0.157 ms with compiler-scheduled loads against
+  // 0.205 with the asm loads + counted wait that help every other shape: they keep the plain loads
+  constexpr bool ASM_LOADS = !(CT == 8 && NT == 1);
   auto load_patch = [&](int tile) __attribute__((always_inline)) {
     int pm = tile;
     const int tx = pm % a.tiles_x;
@@ -135,6 +138,11 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       const bool ok = pch[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       const float* src = (TWO && (pch[j] >> 16)) ? a.x2 : a.x1;
       const int cs = TWO ? 16 : a.C1;
+      if (!ASM_LOADS) {                                          // compiler-scheduled loads (and its own wait in front of store_patch)
+        pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) pr[j] = *reinterpret_cast<const f32x4*>(src + ((size_t)(img * a.H + ih) * a.W + iw) * cs + (pch[j] & 0xFFFF));
+        continue;
+      }
       const float* p = ok ? src + ((size_t)(img * a.H + ih) * a.W + iw) * cs + (pch[j] & 0xFFFF) : g_xn_zero_page;
       // inline asm, one load per piece from every lane (padding and out-of-image pieces read the zero page): outside the compiler's
       // scoreboard -- patch_wait() below is the loads' only wait.  (Exec-masked loads that leave zeros in the padding lanes measured
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
   // one counter for loads and stores), so "vmcnt(number of stores issued since)" = the patch has landed while the stores stay in
   // flight; the compiler's own wait for a register loaded in the previous loop iteration is vmcnt(0), i.e. the stores' round trip
   auto patch_wait = [&](int stores_since) __attribute__((always_inline)) {
+    if (!ASM_LOADS) return;
     constexpr int FULL = MT * NT, FULL_POOL = MT * NT * 3 / 2;       // gfx9 encoding: vmcnt = bits 3:0 and 15:14
     if (stores_since == FULL) __builtin_amdgcn_s_waitcnt(0x0F70 | (FULL & 15) | ((FULL >> 4) << 14));
     else if (stores_since == FULL_POOL) __builtin_amdgcn_s_waitcnt(0x0F70 | (FULL_POOL & 15) | ((FULL_POOL >> 4) << 14));
