@@ -25,6 +25,9 @@
 extern "C" {
 #endif
 
+/* The library reads its SHDR_* environment switches once per process; call this after changing one in a running process. */
+void shdr_config_reload(void);
+
 #define SHDR_OK          0
 #define SHDR_E_SHAPE    (-1)  /* inconsistent / unsupported dimensions          */
 #define SHDR_E_ALIGN    (-2)  /* pointer or channel count not suitably aligned  */
@@ -152,6 +155,17 @@ int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_resid
 int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
                                  const float* bias, const float* scale, const float* shift, const float* residual, float* y,
                                  float* y_pool, void* workspace, void* stream);
+/* The same with RANGE SLOTS (see shdr_conv2d_fwd_x3_f32): x1_range / x2_range = device words holding an upper bound of max |x| of the
+ * sources, or NULL = unknown.  The split-operand plans (SHDR_PLAN_X3 / X3N) scale their input by it; an unknown range is MEASURED here
+ * (one absmax pass over that source into the tail of the workspace: shdr_conv2d_workspace_bytes_f32 accounts for it), so these plans
+ * are as range-safe as the fp32 kernels whatever the caller passes -- shdr_conv2d_fwd_prepared_f32 is this call with three NULLs.
+ * y_range (or NULL): the slot that receives max |y| (atomicMax, the caller zeroes it) -- from the kernel's own epilogue on the
+ * split-operand plans, from one pass over y otherwise -- to be handed to the consumer of y (a pooled / resized / clipped copy of y
+ * has the same bound).  Replaces the fp32 Conv2D call sites of hallucination_net.py:43-75,146-190 and vgg16.py:33-35 at full range. */
+int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                        const float* bias, const float* scale, const float* shift, const float* residual, float* y,
+                                        float* y_pool, void* workspace, const float* x1_range, const float* x2_range, float* y_range,
+                                        void* stream);
 
 /*
  * Convolution backward (GradientTape.gradient through Conv2D: joint_training.py:185,
@@ -385,7 +399,14 @@ int shdr_conv2d_winograd_fused_up2_f32(const float* x, const float* u, const flo
 /* fp32 3x3 / stride-1 / SAME convolution on the fp16 matrix pipe (SHDR_PLAN_X3; csrc/conv_x3.hip): x = xh + xl 2^-11, w 2^S = wh + wl in
  * fp16, x w = xh wh + xl (wh 2^-11) + xh wl accumulated in fp32 -- 3 * 2^-22 relative per product, the level of fp32 rounding itself.
  * Also the 7x7 / stride-2 stem (linearization_net.py:91) as four stride-1 phase launches over the parity-subsampled input, accumulating in y.
- * Needs C1 % 32 == 0, C2 % 32 == 0, Cout % 64 == 0, |x| < 65504.  prepared: shdr_conv2d_x3_filter_elems_f32 floats, written by
+ * Needs C1 % 32 == 0, C2 % 32 == 0, Cout % 64 == 0.  RANGE: fp16 overflows at 65504 and loses mantissa below 2^-14, an fp32 convolution
+ * (hallucination_net.py:47-48, vgg16.py:33-35) does not -- the _ranged entry points take a RANGE SLOT per source (device word: upper
+ * bound of max |x|, from the producer's y_range or shdr_absmax_f32) and scale the input by the power of two that brings it to
+ * [2^10, 2^11) while splitting (exact; undone in the epilogue), and can write the range of their own output (y_range, atomicMax; the
+ * caller zeroes the slot).  Elements down to 2^-25 of the tensor maximum keep 22 mantissa bits; non-finite inputs give non-finite
+ * outputs on their receptive field.  The entry points WITHOUT range slots split the input as it stands (|x| < 65504 required) unless
+ * desc.prologue = SHDR_PROLOGUE_RANGE_SCALE names the slot in the prepared filter's header (shdr_conv2d_x3_input_absmax_f32).
+ * prepared: shdr_conv2d_x3_filter_elems_f32 floats, written by
  * shdr_conv2d_x3_prepare_filter_f32 (the skip scale of the second source folded in).  y = act2(affine(act1(conv + bias)));
  * y_pool (or NULL) = MaxPool2D(2)(y) from the same epilogue (y may then be NULL); desc.prologue = SHDR_PROLOGUE_BILINEAR2X: x1 is the
  * low-res tensor and the 2x bilinear up-sampling runs inside the kernel's patch loader.
@@ -397,6 +418,11 @@ int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w,
 int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                            const float* scale, const float* shift, float* y, float* y_pool, void* stream);
+int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                  const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
+                                  const float* x2_range, float* y_range, void* stream);
+/* range slot of a tensor: *range = max(*range, max |x|) (bit pattern of a non-negative float, atomicMax; the caller zeroes the slot) */
+int shdr_absmax_f32(const float* x, int64_t n, float* range, void* stream);
 
 /* The split-operand arithmetic for the NARROW layers (SHDR_PLAN_X3N; csrc/conv_x3n.hip): stride 1, 3x3 / 5x5 / 7x7 SAME, Cout 16 or 32
  * (cout_valid <= Cout stored), one source of 4 ... 32 channels (C1 % 4 == 0) or two of 16 -- the full-resolution layers of the
@@ -408,6 +434,9 @@ int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d);
 int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream);
 int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                             const float* scale, const float* shift, const float* residual, float* y, float* y_pool, void* stream);
+int shdr_conv2d_fwd_x3n_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                   const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
+                                   const float* x1_range, const float* x2_range, float* y_range, void* stream);
 
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then

@@ -113,16 +113,16 @@ def _dgrad_h(dz, w, c_begin, c_count, scale, stride, x_shape):
     """fp16 input gradient w.r.t. source channels [c_begin, c_begin + c_count) of the forward filter w (fp32 HWIO): the fp16
     conv kernel run on dz with the flipped / transposed filter -- same decomposition as _dgrad (stride 1; 1x1 / 2 on the coarse
     grid; general stride 2 in polyphase form)"""
+    if c_count % 16:
+        raise NotImplementedError("fp16 input gradient needs a multiple of 16 input channels, got %d" % c_count)
     kh, kw = w.shape[0], w.shape[1]
     cz = dz.shape[3]                                   # channels per pixel of dz (>= the filter's true output channels)
     cols = min(w.shape[3], cz)
     if w.shape[3] != cols:                             # zero-padded filter columns carry no gradient
         w = w[..., :cols].contiguous()
     wt = K.filter_transform(w, c_begin, c_count, scale)            # fp32 [kh, kw, cols, c_count]
-    if cz != cols or c_count % 16:
-        wt = F.pad(wt, (0, (-c_count) % 16, 0, cz - cols))
-    if c_count % 16:
-        raise NotImplementedError("fp16 input gradient needs a multiple of 16 input channels, got %d" % c_count)
+    if cz != cols:
+        wt = F.pad(wt, (0, 0, 0, cz - cols))
 
     def run(filt, **kw_):
         return K.conv2d_h(dz, K.pack_filter_h(filt, cz), None, tuple(filt.shape[:2]), filt.shape[3], **kw_)
@@ -426,11 +426,14 @@ class ForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)          # an unused alias contributes nothing: no zero tensor, no add launch for it
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
         gs = [_c(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
         acc = gs[0]
         for g in gs[1:]:
             acc = K.add(acc, g)

@@ -83,7 +83,17 @@ class Layer:
     def to(self, device):
         for n, t, _ in self.named_weights():
             t.data = t.data.to(device)
+            K.clear_filter_caches(t)      # `.data =` does not bump the version: the derived forms kept on the tensor live on the old device
+        self._drop_derived()
         return self
+
+    def _drop_derived(self):
+        """forget per-version derived tensors kept on the layers themselves (padded / composed filters)"""
+        for attr in ("_padded", "_tail"):
+            if getattr(self, attr, None) is not None:
+                object.__setattr__(self, attr, None)
+        for _, child in self._children:
+            child._drop_derived()
 
     def __call__(self, *args, **kwargs):
         return self.call(*args, **kwargs)

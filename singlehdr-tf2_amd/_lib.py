@@ -54,11 +54,15 @@ SIGNATURES = {
     "shdr_conv2d_x3_filter_elems_f32": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_x3_prepare_filter_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_ptr, c_ptr]),
     "shdr_conv2d_fwd_x3_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_conv2d_fwd_x3_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 12),
+    "shdr_absmax_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "shdr_config_reload": (None, []),
     "shdr_conv2d_x3_input_absmax_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "shdr_conv2d_x3n_ok_f32": (c_int, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_x3n_filter_elems_f32": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_x3n_prepare_filter_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_ptr, c_ptr]),
     "shdr_conv2d_fwd_x3n_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 10),
+    "shdr_conv2d_fwd_x3n_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 13),
     "shdr_act_bwd_bias_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_winograd_filter_packed_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_winograd_f32": (c_int, [c_ptr] * 4 + [c_int] * 7 + [c_f32, c_ptr]),
@@ -71,6 +75,7 @@ SIGNATURES = {
     "shdr_conv2d_prepare_filter_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr]),
     "shdr_conv2d_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_fwd_prepared_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 11),
+    "shdr_conv2d_fwd_prepared_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 14),
     "shdr_conv2d_dgrad_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_dgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "shdr_workspace_bytes": (c_i64, [c_int, ctypes.POINTER(ConvDesc), c_int]),

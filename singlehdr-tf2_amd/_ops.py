@@ -121,6 +121,89 @@ def _d(t):
     return None if t is None else t.detach()
 
 
+# ---------------------------------------------------------------------------
+# range slots (include/shdr.h: shdr_conv2d_fwd_prepared_ranged_f32)
+# ---------------------------------------------------------------------------
+# The split-operand conv plans scale their input by a power of two taken from a RANGE SLOT: a device float holding an upper bound of
+# max |x| of the tensor.  The kernels that produce a tensor write its slot from their epilogue (`y_range`), bound-preserving ops
+# (pooling, bilinear resize, clip, channel reversal) hand their input's slot on, host-known bounds become constant slots, and a tensor
+# that arrives without one is measured by the library (one pass over it).  Slots travel as the attribute `_shdr_range` of the tensor.
+_RANGE_SCOPES = []
+_CONST_SLOTS = {}
+
+
+class range_scope:
+    """Slots taken inside the scope come out of ONE zero-initialised slab (one memset per step instead of one per tensor).  The step
+    closures of `pipeline` open a scope per forward and per stream; outside a scope every slot is its own zeroed one-element tensor."""
+
+    SLOTS = 256
+
+    def __enter__(self):
+        self._slab, self._n = None, 0
+        _RANGE_SCOPES.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _RANGE_SCOPES.remove(self)
+        return False
+
+    def take(self, device):
+        if self._slab is None or self._n == self.SLOTS or self._slab.device != device:
+            self._slab, self._n = torch.zeros(self.SLOTS, device=device, dtype=torch.float32), 0
+        self._n += 1
+        return self._slab[self._n - 1:self._n]
+
+
+def _new_slot(device):
+    if _RANGE_SCOPES:
+        return _RANGE_SCOPES[-1].take(device)
+    return torch.zeros(1, device=device, dtype=torch.float32)
+
+
+def _range_of(t):
+    """the range slot of a tensor (1-element fp32 device tensor) or None; a host-known bound (`_shdr_bound`) becomes a constant slot"""
+    if t is None:
+        return None
+    r = getattr(t, "_shdr_range", None)
+    if r is not None:
+        return r
+    b = getattr(t, "_shdr_bound", None)
+    if b is None:
+        return None
+    key = (t.device, float(b))
+    slot = _CONST_SLOTS.get(key)
+    if slot is None:
+        slot = _CONST_SLOTS[key] = torch.full((1,), float(b), device=t.device, dtype=torch.float32)
+    return slot
+
+
+def _carry_range(y, x, factor=None):
+    """y is bounded by x's bound (pooling, convex resampling, channel permutation, clipping of an already bounded tensor)"""
+    r = getattr(x, "_shdr_range", None)
+    if r is not None:
+        y._shdr_range = r
+    b = getattr(x, "_shdr_bound", None)
+    if b is not None:
+        y._shdr_bound = b
+    return y
+
+
+def set_bound(t, bound):
+    """declare a host-known upper bound of max |t| (e.g. an image in [0, 1])"""
+    t._shdr_bound = float(bound)
+    return t
+
+
+def absmax_slot(x):
+    """measure max |x| into a fresh range slot and attach it to x"""
+    lib = _lib.load()
+    xd = _chk(_d(x), "x")
+    slot = _new_slot(xd.device)
+    _lib.check(lib.shdr_absmax_f32(_ptr(xd), xd.numel(), _ptr(slot), _stream()), "shdr_absmax_f32")
+    x._shdr_range = slot
+    return slot
+
+
 def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scale=None,
            shift=None, residual=None, act2=ACT_NONE, algo=ALGO_AUTO, out=None, cout_valid=None,
            pad=None, out_hw=None, w_batch_stride=0):
@@ -174,6 +257,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     caches the prepared filter of persistent variables per version and provides memory.  pool: None, True (also return
     MaxPool2D(2)(y)), "only" (the pooled tensor alone) or "avg" (also return AveragePooling2D(2)(y))."""
     lib = _lib.load()
+    x_in, x2_in = x, x2                # the tensors as handed over: they carry the range slots (a detached copy does not)
     x = _chk(_d(x), "x")
     w_var = w                          # the variable itself: its version / leaf status key the prepared-filter cache
     w = _chk(_d(w), "w")
@@ -235,45 +319,101 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
         return out
     has_res = int(residual is not None)
     prepared = _prepared_filter(lib, w_var, d, has_res)
+    plan = int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res))
+    split = plan in (4, 5)             # SHDR_PLAN_X3 / X3N: the input is scaled by its range, the epilogue tracks the output's
+    xr1 = _range_of(x_in) if split else None
+    xr2 = _range_of(x2_in) if (split and x2 is not None) else None
+    yr = _new_slot(x.device) if split else None
     ws = None
     nws = int(lib.shdr_conv2d_workspace_bytes_f32(ctypes.byref(d), has_res))
-    if nws > 0:
-        ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
+    if nws > 256 or (nws > 0 and (not split or xr1 is None or (x2 is not None and xr2 is None))):
+        ws = torch.empty(nws, device=x.device, dtype=torch.uint8)      # (a split plan with known ranges needs no scratch slots)
     yp = None
     if pool:
         if ho % 2 or wo % 2:
             raise ValueError("conv2d: pool needs even output height / width")
         yp = torch.empty((n, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
-        if out is None and int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)) not in (2, 4):      # the fused Winograd and split kernels can skip y
+        if out is None and plan not in (2, 4):      # the fused Winograd and split kernels can skip y
             out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
-    rc = lib.shdr_conv2d_fwd_prepared_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
-                                          _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _stream())
-    _lib.check(rc, "shdr_conv2d_fwd_prepared_f32")
+    rc = lib.shdr_conv2d_fwd_prepared_ranged_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
+                                                 _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _ptr(xr1), _ptr(xr2),
+                                                 _ptr(yr), _stream())
+    _lib.check(rc, "shdr_conv2d_fwd_prepared_ranged_f32")
+    if yr is not None:
+        for t in (out, yp):
+            if t is not None:
+                t._shdr_range = yr         # (the pooled copy is bounded by the same maximum)
     if pool == "only":
         return yp
     return (out, yp) if pool else out
 
 
+def _is_persistent(w):
+    """requires_grad leaves (the layers' kernels) and frozen constants (_shdr_const: VGG16, padded / composed filters)"""
+    return (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)
+
+
+def _filter_cache_get(w, attr, key):
+    """Derived forms of a persistent filter (prepared / packed / fp16-packed) live ON the filter tensor in a dict
+    {key: (tensor, producing stream, ready event)} tagged with the variable's version.  Entries are dropped only when the version
+    changes: the same weight takes different plans at different input shapes (x3 needs >= 192 blocks, x3n >= 256 tiles), and a
+    captured HIP graph holds the raw pointer of the form it was captured with -- evicting one shape's form for another's would
+    leave that graph reading freed memory.  A consumer on another stream than the producer waits for the producer's event."""
+    store = getattr(w, attr, None)
+    if store is None or store[0] != w._version:
+        return None
+    ent = store[1].get(key)
+    if ent is None:
+        return None
+    tensor, stream_id, event = ent
+    # (no event calls while a stream capture is open: hipEventQuery invalidates the capture; GraphedInference warms the caches up first)
+    if event is not None and torch.cuda.current_stream().cuda_stream != stream_id and not torch.cuda.is_current_stream_capturing() \
+            and not event.query():
+        torch.cuda.current_stream().wait_event(event)
+    return tensor
+
+
+def _filter_cache_put(w, attr, key, tensor):
+    store = getattr(w, attr, None)
+    if store is None or store[0] != w._version:
+        store = (w._version, {})
+        setattr(w, attr, store)
+    event = None
+    if not torch.cuda.is_current_stream_capturing():
+        event = torch.cuda.Event()
+        event.record()
+    store[1][key] = (tensor, torch.cuda.current_stream().cuda_stream, event)
+    return tensor
+
+
+def clear_filter_caches(w):
+    """forget every derived form kept on a filter tensor (the tensor moved to another device, or was rewritten behind torch's back)"""
+    for attr in ("_shdr_packed", "_shdr_packed_h", "_shdr_wino"):
+        if hasattr(w, attr):
+            delattr(w, attr)
+
+
 def _prepared_filter(lib, w, d, has_res):
     """shdr_conv2d_prepare_filter_f32(w) for the plan of this layer -- `w` itself when the library says the prepared form is the
-    plain filter; kept ON the filter tensor per version for persistent variables (requires_grad leaves: the layers' kernels,
-    frozen VGG16 constants), so an inference step prepares nothing; temporaries (transposed dgrad filters) per call.  Every kernel
-    that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
+    plain filter; kept ON the filter tensor per version and per (plan, sources, skip scale) for persistent variables
+    (requires_grad leaves: the layers' kernels, frozen VGG16 constants), so an inference step prepares nothing; temporaries
+    (transposed dgrad filters) per call.  Every kernel that rewrites a variable through a raw pointer bumps its version
+    (_mutated, KerasAdam)."""
     if int(lib.shdr_conv2d_filter_is_plain_f32(ctypes.byref(d), has_res)):
         return _d(w)
-    persistent = (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)
+    persistent = _is_persistent(w)
     key = None
     if persistent:
-        key = (w._version, int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)), d.C1, d.C2, float(d.x2_scale))
-        cached = getattr(w, "_shdr_packed", None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        key = (int(lib.shdr_conv2d_plan_f32(ctypes.byref(d), has_res)), d.C1, d.C2, float(d.x2_scale))
+        cached = _filter_cache_get(w, "_shdr_packed", key)
+        if cached is not None:
+            return cached
     n = int(lib.shdr_conv2d_prepared_filter_elems_f32(ctypes.byref(d), has_res))
     prepared = torch.empty(n, device=w.device, dtype=torch.float32)
     _lib.check(lib.shdr_conv2d_prepare_filter_f32(ctypes.byref(d), has_res, _ptr(_d(w)), _ptr(prepared), _stream()),
                "shdr_conv2d_prepare_filter_f32")
     if persistent:
-        w._shdr_packed = (key, prepared)
+        _filter_cache_put(w, "_shdr_packed", key, prepared)
     return prepared
 
 
@@ -344,6 +484,7 @@ def soft_hist_bwd(img, dy, max_bin):
 
 def _nhwc_op(fn_name, x, out_shape):
     lib = _lib.load()
+    x_in = x
     if _is_h(x):                       # the _f16 twin (csrc/elem_f16.hip)
         x = _chkh(_d(x), "x")
         fn_name = fn_name[:-4] + "_f16"
@@ -353,7 +494,7 @@ def _nhwc_op(fn_name, x, out_shape):
     y = torch.empty(out_shape, device=x.device, dtype=x.dtype)
     rc = getattr(lib, fn_name)(_ptr(x), _ptr(y), n, h, w, c, _stream())
     _lib.check(rc, fn_name)
-    return y
+    return _carry_range(y, x_in)        # pooling / bilinear resize: bounded by the input's maximum
 
 
 def avgpool2(x):
@@ -416,6 +557,7 @@ def lin_frontend(img, channels=96, dtype=None):
     if _needs_grad(img):
         return AUTOGRAD.lin_frontend(img, channels, dtype)
     lib = _lib.load()
+    img_in = img
     img = _chk(_d(img), "img")
     n, h, w, c = img.shape
     if c != 3:
@@ -423,6 +565,9 @@ def lin_frontend(img, channels=96, dtype=None):
     y = torch.empty((n, h, w, channels), device=img.device, dtype=dtype)
     fn = "shdr_lin_frontend_fwd_f16" if dtype == HALF else "shdr_lin_frontend_fwd_f32"
     _lib.check(getattr(lib, fn)(_ptr(img), _ptr(y), n, h, w, channels, _stream()), fn)
+    b = getattr(img_in, "_shdr_bound", None)
+    if b is not None:                  # image: b, sobel: sum |coefficient| = 8 times b, soft-histogram channels: [0, 1]
+        set_bound(y, max(1.0, 8.0 * b))
     return y
 
 
@@ -476,7 +621,7 @@ def clip(x, lo, hi):
     y = torch.empty_like(x)
     _lib.check(lib.shdr_clip_fwd_f32(_ptr(x), _ptr(y), x.numel(), float(lo), float(hi), _stream()),
                "shdr_clip_fwd_f32")
-    return y
+    return set_bound(y, max(abs(float(lo)), abs(float(hi))))
 
 
 def logc(x):
@@ -502,6 +647,7 @@ def vgg_preprocess(x, out_channels=3, dtype=torch.float32):
     if _needs_grad(x):
         return AUTOGRAD.vgg_preprocess(x, out_channels, dtype)
     lib = _lib.load()
+    x_in = x
     x, npix = _pix3(x, "x")
     if dtype == HALF:
         y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=HALF)
@@ -510,6 +656,9 @@ def vgg_preprocess(x, out_channels=3, dtype=torch.float32):
     y = torch.empty(tuple(x.shape[:-1]) + (out_channels,), device=x.device, dtype=torch.float32)
     _lib.check(lib.shdr_vgg_preprocess_fwd_f32(_ptr(x), _ptr(y), npix, out_channels, _stream()),
                "shdr_vgg_preprocess_fwd_f32")
+    b = getattr(x_in, "_shdr_bound", None)
+    if b is not None:
+        set_bound(y, 255.0 * b + 124.0)     # x * 255 - mean, |mean| < 124
     return y
 
 
@@ -1115,11 +1264,11 @@ def pack_filter_h(w, c1, c2=0, x2_scale=1.0):
     """fp32 HWIO filter -> the packed fp16 filter of conv2d_h ([k-chunk][Cout][32]; x2_scale folded into the x2 rows); kept ON
     the filter tensor per version for persistent variables, like the packed Winograd filters"""
     key = None
-    if (w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False):
-        key = (w._version, c1, c2, float(x2_scale))
-        cached = getattr(w, "_shdr_packed_h", None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+    if _is_persistent(w):
+        key = (c1, c2, float(x2_scale))
+        cached = _filter_cache_get(w, "_shdr_packed_h", key)
+        if cached is not None:
+            return cached
     lib = _lib.load()
     wd = _chk(_d(w), "w")
     kh, kw, cin, cout = wd.shape
@@ -1130,7 +1279,7 @@ def pack_filter_h(w, c1, c2=0, x2_scale=1.0):
     _lib.check(lib.shdr_conv2d_pack_filter_f16(_ptr(wd), _ptr(wp), kh, kw, c1, c2, cout, float(x2_scale), _stream()),
                "shdr_conv2d_pack_filter_f16")
     if key is not None:
-        w._shdr_packed_h = (key, wp)
+        _filter_cache_put(w, "_shdr_packed_h", key, wp)
     return wp
 
 
@@ -1280,14 +1429,12 @@ def _packed_filter(w):
     """winograd_filter_packed(w), kept ON the filter tensor per version for persistent variables (requires_grad leaves: the
     layers' kernels): an inference step then packs nothing (33 launches per step).  Temporaries (transposed dgrad filters)
     are packed per call.  Every kernel that rewrites a variable through a raw pointer bumps its version (_mutated, KerasAdam)."""
-    if not ((w.requires_grad and w.is_leaf) or getattr(w, "_shdr_const", False)):     # _shdr_const: frozen weights (VGG16)
+    if not _is_persistent(w):                      # _shdr_const: frozen weights (VGG16)
         return winograd_filter_packed(w)
-    cached = getattr(w, "_shdr_packed", None)
-    if cached is not None and cached[0] == w._version:
-        return cached[1]
-    u = winograd_filter_packed(w)
-    w._shdr_packed = (w._version, u)
-    return u
+    cached = _filter_cache_get(w, "_shdr_wino", "u")
+    if cached is not None:
+        return cached
+    return _filter_cache_put(w, "_shdr_wino", "u", winograd_filter_packed(w))
 
 
 def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):

@@ -15,6 +15,11 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace shdr
 
+namespace shdr {
+int g_env_epoch = 0;
+}
+extern "C" void shdr_config_reload(void) { __atomic_add_fetch(&shdr::g_env_epoch, 1, __ATOMIC_ACQ_REL); }
+
 extern "C" const char* shdr_last_error(void) { return shdr::g_last_error; }
 extern "C" const char* shdr_version(void) { return "libshdr 0.1 gfx950"; }
 

@@ -798,7 +798,7 @@ inline int reduce_grid(long npix, int C) {
 inline void launch_bn_reduce(hipStream_t st, const float* a, const float* x, const float* y, const float* mean, double* ws,
                              long npix, int C, int mode) {
   const bool vec = C % 4 == 0 && shdr::aligned16(a) && (!x || shdr::aligned16(x)) && (!y || shdr::aligned16(y)) &&
-                   (!mean || shdr::aligned16(mean)) && getenv("SHDR_BN_SCALAR") == nullptr;
+                   (!mean || shdr::aligned16(mean)) && SHDR_ENV("SHDR_BN_SCALAR") == nullptr;
   if (vec) {
     const int Q = C / 4;
     int QL = 1;
@@ -936,7 +936,7 @@ extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_r
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, var, dgamma, dbeta, C, eps);
   const int Q = C / 4;
   if (C % 4 == 0 && (Q & (Q - 1)) == 0 && Q <= 4096 && shdr::aligned16(dy) && shdr::aligned16(x) && shdr::aligned16(dx) &&
-      (!y_relu || shdr::aligned16(y_relu)) && getenv("SHDR_BN_SCALAR") == nullptr) {
+      (!y_relu || shdr::aligned16(y_relu)) && SHDR_ENV("SHDR_BN_SCALAR") == nullptr) {
     long grid = shdr::stream_grid(npix * Q);
     const long unit = Q > 256 ? Q / 256 : 1;              // grid * 256 must be a multiple of Q
     grid = (grid + unit - 1) / unit * unit;

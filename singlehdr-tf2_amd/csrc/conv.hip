@@ -978,7 +978,7 @@ int launch_rega(ConvArgs& a, hipStream_t st) {
     occ_lds = lds;
   }
   long grid = 256L * occ;
-  if (const char* e = getenv("SHDR_REGA_PER_CU")) grid = 256L * atoi(e);
+  if (const char* e = SHDR_ENV("SHDR_REGA_PER_CU")) grid = 256L * atoi(e);
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((conv_rega_kernel<MT, NT, CT, KK>), dim3((unsigned)grid), dim3(256), lds, st, a);
   return shdr::check_launch("conv_rega_kernel");
@@ -989,7 +989,7 @@ inline bool rega_ok(const ConvArgs& a) {
   if (a.stride != 1 || a.w_bstride != 0 || a.Cout % 16 != 0) return false;
   // 64 output channels only from a 4-channel (RGB + zero) source: the first layer of the VGG-shaped encoders (0.76 -> 0.54 ms
   // at 16 x 512^2; a per-wave LDS-staged, row-contiguous store on top of it measured no further gain)
-  if (a.Cout > 32 && !(a.Cout == 64 && a.C2 == 0 && a.C1 == 4 && a.KH == 3 && a.KW == 3 && getenv("SHDR_NO_REGA64") == nullptr)) return false;
+  if (a.Cout > 32 && !(a.Cout == 64 && a.C2 == 0 && a.C1 == 4 && a.KH == 3 && a.KW == 3 && SHDR_ENV("SHDR_NO_REGA64") == nullptr)) return false;
   const bool ct4 = a.C2 == 0 && a.C1 == 4, ct16 = a.C2 == 0 && (a.C1 == 8 || a.C1 == 12 || a.C1 == 16);
   const bool ct32 = (a.C2 == 0 && a.C1 == 32) || (a.C1 == 16 && a.C2 == 16);
   if (!(ct4 || ct16 || ct32)) return false;
@@ -999,7 +999,7 @@ inline bool rega_ok(const ConvArgs& a) {
 
 template <int NT, int CT>
 int dispatch_rega_k(ConvArgs& a, hipStream_t st) {
-  const bool square = a.KH == a.KW && getenv("SHDR_REGA_NO_DPP") == nullptr;
+  const bool square = a.KH == a.KW && SHDR_ENV("SHDR_REGA_NO_DPP") == nullptr;
   if (square && a.KH == 3) return launch_rega<4, NT, CT, 3>(a, st);
   if (square && a.KH == 5) return launch_rega<4, NT, CT, 5>(a, st);
   if (square && a.KH == 7) return launch_rega<4, NT, CT, 7>(a, st);
@@ -1087,7 +1087,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
     a.YH = d->y_H; a.YW = d->y_W; a.ys = d->y_pix_stride; a.yoh = d->y_off_h; a.yow = d->y_off_w;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  a.legacy_epilogue = getenv("SHDR_CONV_LEGACY_EPILOGUE") != nullptr;
+  a.legacy_epilogue = SHDR_ENV("SHDR_CONV_LEGACY_EPILOGUE") != nullptr;
 
   const bool ragged = (cout_valid % 4) != 0;  // scalar epilogue: no alignment demands on y/res/bias
   const bool mfma_ok = (a.C1 % 4 == 0) && (a.C2 % 4 == 0) && (a.Cout % 16 == 0) &&
@@ -1115,7 +1115,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
     // stay on the fp16 kernel (0.53 vs 0.57, 0.24 vs 0.30 ms).
     const bool auto_reduced = d->algo == SHDR_ALGO_AUTO_F16 || d->algo == SHDR_ALGO_AUTO_BF16;
     const bool rega_prec = a.prec == 0 || (auto_reduced && a.C2 == 0 && (a.Cout == 16 || a.Cout == 64));
-    const bool rega = rega_prec && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && getenv("SHDR_NO_REGA") == nullptr;
+    const bool rega = rega_prec && !a.no_dma && d->algo != SHDR_ALGO_MFMA && rega_ok(a) && SHDR_ENV("SHDR_NO_REGA") == nullptr;
     if (rega) a.prec = 0;
     if (rega && a.Cout == 64) return launch_rega<4, 4, 4, 3>(a, st);
     if (a.Cout % 64 == 0) return launch_mfma<128, 64, 4, 1>(a, st);

@@ -197,7 +197,7 @@ extern "C" int shdr_conv2d_w3_ok_f16(const shdr_conv2d_desc* d) {
   // enough blocks to fill the chip: the deepest, smallest maps stay on the 128 x 128 implicit-GEMM tiles
   const long blocks = (long)d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16) * (d->Cout / 64);
   long min_blocks = 384;
-  if (const char* e = getenv("SHDR_W3_MIN_BLOCKS")) min_blocks = atol(e);
+  if (const char* e = SHDR_ENV("SHDR_W3_MIN_BLOCKS")) min_blocks = atol(e);
   return blocks >= min_blocks ? 1 : 0;
 }
 

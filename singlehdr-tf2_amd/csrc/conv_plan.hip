@@ -32,13 +32,13 @@ int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   shdr_same_pad(d->W, d->KW, d->stride, &wo, &pl);
   const bool same = d->pad_t == pt && d->pad_l == pl && d->Ho == ho && d->Wo == wo;
   const bool wino_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && same && !has_residual && cout_valid == d->Cout &&
-                          d->w_batch_stride == 0 && d->y_pix_stride <= 1 && getenv("SHDR_NO_WINOGRAD") == nullptr;
+                          d->w_batch_stride == 0 && d->y_pix_stride <= 1 && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr;
   // the narrow layers of the U-Nets (Cout 16 / 32, <= 32 channels per tap): the split-operand arithmetic with the whole filter in LDS;
   // its epilogue takes a residual
-  if (d->algo == SHDR_ALGO_AUTO && same && getenv("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3n_ok_f32(d)) return SHDR_PLAN_X3N;
+  if (d->algo == SHDR_ALGO_AUTO && same && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3n_ok_f32(d)) return SHDR_PLAN_X3N;
   // the split-operand fp16 kernel first (1.4-1.5x the fused Winograd kernel's rate, same accuracy class; also the 7x7 / 2 stem);
   // SHDR_ALGO_AUTO_EXACT opts out
-  if (d->algo == SHDR_ALGO_AUTO && !has_residual && same && getenv("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
+  if (d->algo == SHDR_ALGO_AUTO && !has_residual && same && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
   if (wino_shape) {
     const bool two_ok = d->C2 == 0 || (d->C2 == d->C1 && d->C1 % 8 == 0 && d->x2_scale == 1.0f);
     if (two_ok && Ct % 8 == 0 && d->Cout % 64 == 0 && Ct >= 32 && (long)d->N * d->H * d->W * Ct < (1L << 32)) return SHDR_PLAN_WINOGRAD_FUSED;
@@ -103,7 +103,7 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
   g.CC = g.c_count % 16 == 0 ? g.c_count : (g.c_count + 15) / 16 * 16;
   // stride-1 3x3 layers take the fused Winograd kernel when the transposed shape qualifies (the rule of plan_of)
   g.wino = is_auto(d->algo) && d->stride == 1 && d->KH == 3 && d->KW == 3 && !g.pad_dz && g.CC == g.c_count && g.CZ % 8 == 0 && g.CC % 64 == 0 && g.CZ >= 32 &&
-           (long)d->N * d->Ho * d->Wo * g.CZ < (1L << 32) && getenv("SHDR_NO_WINOGRAD") == nullptr;
+           (long)d->N * d->Ho * d->Wo * g.CZ < (1L << 32) && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr;
   // ... and the split-operand fp16 kernel before it, by the rule of plan_of on the transposed convolution
   g.x3 = false;
   if (g.wino && d->algo == SHDR_ALGO_AUTO && g.CZ % 32 == 0) {
@@ -115,7 +115,7 @@ DgradGeom dgrad_geom(const shdr_conv2d_desc* d, int which) {
   // the narrow stride-1 layers of the U-Nets: the split-operand kernel with the whole (transposed) filter in LDS
   g.x3n = false;
   shdr_conv2d_desc tn{};
-  if (d->algo == SHDR_ALGO_AUTO && d->stride == 1 && d->KH == d->KW && !g.pad_dz && getenv("SHDR_NO_WINOGRAD") == nullptr) {
+  if (d->algo == SHDR_ALGO_AUTO && d->stride == 1 && d->KH == d->KW && !g.pad_dz && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr) {
     tn.N = d->N; tn.H = d->Ho; tn.W = d->Wo; tn.C1 = g.CZ; tn.Cout = g.CC; tn.KH = d->KH; tn.KW = d->KW; tn.stride = 1;
     tn.pad_t = (d->KH - 1) - d->pad_t; tn.pad_l = (d->KW - 1) - d->pad_l; tn.Ho = d->H; tn.Wo = d->W; tn.cout_valid = g.c_count;
     g.x3n = shdr_conv2d_x3n_ok_f32(&tn) != 0;
@@ -178,7 +178,7 @@ extern "C" int shdr_conv2d_prepare_filter_f32(const shdr_conv2d_desc* d, int has
 // 128 -> 64 2.70 -> 2.03 ms, 256 -> 128 2.13 -> 1.88, 512 -> 256 1.86 -> 1.79, 512 -> 512 0.91 -> 0.96: fused up to 256 couts
 inline bool up2_in_kernel(const shdr_conv2d_desc* d, int plan) {
   if (d->C2 != 0) return false;
-  if (plan == SHDR_PLAN_X3) return d->KH == 3 && d->stride == 1 && (d->Cout <= 256 || getenv("SHDR_X3_UP_ALWAYS") != nullptr);
+  if (plan == SHDR_PLAN_X3) return d->KH == 3 && d->stride == 1 && (d->Cout <= 256 || SHDR_ENV("SHDR_X3_UP_ALWAYS") != nullptr);
   return plan == SHDR_PLAN_WINOGRAD_FUSED;
 }
 // bytes of the materialised up-sampled tensor in front of the plan's own workspace (0 when the prologue is fused or absent)
@@ -187,34 +187,73 @@ inline size_t up2_bytes(const shdr_conv2d_desc* d, int plan) {
   return up256((size_t)d->N * d->H * d->W * d->C1 * sizeof(float));
 }
 
+// The split-operand plans scale their input by a power of two taken from a RANGE SLOT per source (conv_x3.hip "Range").  A caller that
+// does not know the range of a source (x1_range / x2_range = NULL) gets it measured here: one absmax pass over that source into two
+// scratch slots at the tail of the workspace.
+constexpr size_t kRangeScratch = 256;
+inline bool split_plan(int plan) { return plan == SHDR_PLAN_X3 || plan == SHDR_PLAN_X3N; }
+
 extern "C" int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, int has_residual) {
   if (!d) return -1;
   const int plan = plan_of(d, has_residual != 0);
   const size_t up = up2_bytes(d, plan);
+  if (split_plan(plan)) return (int64_t)(up + kRangeScratch);
   if (plan != SHDR_PLAN_WINOGRAD_PLANES) return (int64_t)up;
   const int64_t rows = shdr_winograd_tiles(d->N, d->H, d->W);          // rows of each of the 16 transform planes
   return (int64_t)(up + up256((size_t)16 * rows * (d->C1 + d->C2) * sizeof(float)) + up256((size_t)16 * rows * d->Cout * sizeof(float)));
 }
 
-extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                            const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
-                                            void* workspace, void* stream) {
+extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                                   const float* bias, const float* scale, const float* shift, const float* residual, float* y,
+                                                   float* y_pool, void* workspace, const float* x1_range, const float* x2_range,
+                                                   float* y_range, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_fwd_prepared: null desc / x1 / prepared filter / output");
   SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared: the fused 2x2 pooling needs even Ho, Wo");
   SHDR_REQUIRE(d->pool == SHDR_POOL_MAX || d->pool == SHDR_POOL_AVG, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown pool kind");
   const int plan = plan_of(d, residual != nullptr);
   const bool avg = y_pool && d->pool == SHDR_POOL_AVG;
+  if (split_plan(plan) && (!x1_range || (x2 && !x2_range))) {
+    // unknown input range: measured (the split-operand kernels never run unscaled from here)
+    SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL,
+                 "conv2d_fwd_prepared: a split-operand layer without x ranges needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
+    float* slots = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shdr_conv2d_workspace_bytes_f32(d, residual != nullptr) - kRangeScratch);
+    if (hipMemsetAsync(slots, 0, 2 * sizeof(float), S(stream)) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_fwd_prepared: memset failed");
+    const bool lowres = d->prologue == SHDR_PROLOGUE_BILINEAR2X;           // x1 is the low-res tensor; bilinear weights are convex: same bound
+    const int64_t npix = (int64_t)d->N * (lowres ? d->H / 2 : d->H) * (lowres ? d->W / 2 : d->W);
+    if (!x1_range) {
+      if (int rcm = shdr_absmax_f32(x1, npix * d->C1, slots, stream)) return rcm;
+      x1_range = slots;
+    }
+    if (x2 && !x2_range) {
+      if (int rcm = shdr_absmax_f32(x2, npix * d->C2, slots + 1, stream)) return rcm;
+      x2_range = slots + 1;
+    }
+  }
+  if (y_range && !split_plan(plan)) {
+    // plans whose epilogue does not track the output range: one pass over the output(s) after the convolution
+    SHDR_REQUIRE(d->y_pix_stride <= 1 && (d->y_cstride == 0 || d->y_cstride == (d->cout_valid > 0 ? d->cout_valid : d->Cout)), SHDR_E_SHAPE,
+                 "conv2d_fwd_prepared: y_range needs a dense output");
+    if (int rcc = shdr_conv2d_fwd_prepared_ranged_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, y_pool, workspace, x1_range, x2_range,
+                                                      nullptr, stream))
+      return rcc;
+    const int64_t cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
+    if (y) return shdr_absmax_f32(y, (int64_t)d->N * d->Ho * d->Wo * cv, y_range, stream);
+    return shdr_absmax_f32(y_pool, (int64_t)d->N * (d->Ho / 2) * (d->Wo / 2) * cv, y_range, stream);
+  }
   if (avg && (plan == SHDR_PLAN_WINOGRAD_FUSED || (d->prologue == SHDR_PROLOGUE_BILINEAR2X && plan != SHDR_PLAN_X3))) {
     // the Winograd kernel's epilogue pools by maximum only: convolution, then the pooling launch
     SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: this plan writes y before it pools");
-    if (int rcw = shdr_conv2d_fwd_prepared_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, nullptr, workspace, stream)) return rcw;
+    if (int rcw = shdr_conv2d_fwd_prepared_ranged_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, nullptr, workspace, x1_range, x2_range,
+                                                      y_range, stream))
+      return rcw;
     return shdr_avgpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, d->Cout, stream);
   }
   if (d->prologue != SHDR_PROLOGUE_NONE) {
     SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_BILINEAR2X, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown prologue");
     SHDR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->C2 == 0 && x2 == nullptr, SHDR_E_SHAPE,
                  "conv2d_fwd_prepared: the bilinear 2x prologue takes one source and even (up-sampled) H, W");
-    if (plan == SHDR_PLAN_X3 && up2_in_kernel(d, plan)) return shdr_conv2d_fwd_x3_f32(d, x1, nullptr, prepared, bias, scale, shift, y, y_pool, stream);
+    if (plan == SHDR_PLAN_X3 && up2_in_kernel(d, plan))
+      return shdr_conv2d_fwd_x3_ranged_f32(d, x1, nullptr, prepared, bias, scale, shift, y, y_pool, x1_range, nullptr, y_range, stream);
     if (up2_in_kernel(d, plan)) {
       SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: the bilinear 2x prologue writes y");
       int rcf = shdr_conv2d_winograd_fused_up2_f32(x1, prepared, bias, scale, shift, y, d->N, d->H, d->W, d->C1, d->Cout, d->act1, d->act2, stream);
@@ -228,18 +267,20 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
     if (rcu) return rcu;
     shdr_conv2d_desc g = *d;
     g.prologue = SHDR_PROLOGUE_NONE;
-    return shdr_conv2d_fwd_prepared_f32(&g, xu, nullptr, prepared, bias, scale, shift, residual, y, y_pool,
-                                        reinterpret_cast<char*>(workspace) + up256((size_t)d->N * d->H * d->W * d->C1 * sizeof(float)), stream);
+    return shdr_conv2d_fwd_prepared_ranged_f32(&g, xu, nullptr, prepared, bias, scale, shift, residual, y, y_pool,
+                                               reinterpret_cast<char*>(workspace) + up256((size_t)d->N * d->H * d->W * d->C1 * sizeof(float)),
+                                               x1_range, nullptr, y_range, stream);
   }
   if (plan == SHDR_PLAN_WINOGRAD_FUSED)
     return shdr_conv2d_winograd_fused2_f32(x1, x2, prepared, bias, scale, shift, y, y_pool, d->N, d->H, d->W, d->C1, d->C2, d->Cout, d->act1,
                                            d->act2, stream);
-  if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, stream);
+  if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_ranged_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, x1_range, x2_range, y_range, stream);
   SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd and split-operand paths");
   int rc;
   if (plan == SHDR_PLAN_X3N) {
     const bool in_kernel = y_pool && d->y_pix_stride <= 1 && (d->cout_valid == 0 || d->cout_valid == d->Cout);
-    rc = shdr_conv2d_fwd_x3n_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, in_kernel ? y_pool : nullptr, stream);
+    rc = shdr_conv2d_fwd_x3n_ranged_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, in_kernel ? y_pool : nullptr, x1_range, x2_range, y_range,
+                                        stream);
     if (rc || in_kernel) return rc;
   } else if (plan == SHDR_PLAN_WINOGRAD_PLANES) {
     SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL, "conv2d_fwd_prepared: this layer needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
@@ -267,6 +308,13 @@ extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const flo
     return avg ? shdr_avgpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream) : shdr_maxpool2_fwd_f32(y, y_pool, d->N, d->Ho, d->Wo, cv, stream);
   }
   return SHDR_OK;
+}
+
+// the same without range slots: every split-operand layer measures its input range (one pass over x per source)
+extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                            const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
+                                            void* workspace, void* stream) {
+  return shdr_conv2d_fwd_prepared_ranged_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, y_pool, workspace, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int64_t shdr_conv2d_dgrad_workspace_bytes_f32(const shdr_conv2d_desc* d, int which) {

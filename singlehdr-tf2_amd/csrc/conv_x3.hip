@@ -11,8 +11,14 @@
 // four v_pk_mul_f16 -- one LDS image and a third of the filter bytes less than a stored copy) and wl, all into ONE fp32 accumulator; the
 // epilogue multiplies by 2^-S (exact).  Per-product error <= 3 * 2^-22 = 7e-7 relative, of random sign -- the level of the fp32
 // rounding of a K >= 288 dot product itself; measured against the float64 oracle in tests/test_gpu_ops.py (same 1e-5 bar as the
-// exact-fp32 kernels, errors reported next to the Winograd kernel's).  |x| must stay below 65504 (fp16 range): activations of
-// these nets are O(1) ... O(1e3); larger values give inf / nan, loudly.
+// exact-fp32 kernels, errors reported next to the Winograd kernel's).
+// Range.  fp16(x) overflows at |x| >= 65504 and loses the high term's mantissa below 2^-14, which an fp32 convolution does not.  Every
+// launch therefore takes a RANGE SLOT per source -- a device word holding (the bit pattern of) an upper bound of max |x| of the tensor,
+// written by the producing kernel's epilogue (y_range of the conv kernels), by shdr_absmax_f32, or known to the host -- and multiplies
+// the input by the power of two 2^T that brings that bound into [2^10, 2^11) while it splits (one v_fma_mix per term: the scaling costs
+// no instruction), the epilogue multiplies by 2^-T: both exact.  Elements down to 2^-25 of the tensor's maximum keep all 22 bits, smaller
+// ones an absolute precision of 2^-46 of the maximum; non-finite inputs give non-finite outputs on their receptive field, as the fp32
+// kernels do.  A launch without a slot (the low-level entry point only) runs unscaled.
 //
 // Kernel (the layout of conv_f16_w3.hip with fp32 tensors in HBM): block = 16 x 16 pixels x 64 couts, 4 waves; per 32-channel chunk
 // the raw 18 x 18 fp32 patch is loaded ONCE into registers (coalesced 128-byte lines, issued under the MFMAs of the previous
@@ -70,7 +76,55 @@ struct X3Args {
   int in_s, bh, bw;        // stride-1 3x3 SAME: in_s = 1, bh = bw = -1
   int final;               // 0: store the raw partial sum (another phase follows), 1: the epilogue
   int pool_avg;            // yp = AveragePooling2D(2)(y) instead of MaxPool2D(2)(y)
+  const unsigned* xr1;     // range slots of the two sources (bits of an upper bound of max |x|; null: no scaling)
+  const unsigned* xr2;
+  unsigned* yr;            // range slot of the output: atomicMax of max |y| (null: not wanted)
 };
+
+// 2^T and 2^-T for the power of two that brings the larger of the two bounds into [2^10, 2^11); 1 for an empty, zero or non-finite bound
+__device__ __forceinline__ void x3_range_scale(const unsigned* r1, const unsigned* r2, float& xs, float& ixs) {
+  xs = 1.0f;
+  ixs = 1.0f;
+  unsigned b = r1 ? *r1 : 0u;
+  if (r2) {
+    const unsigned b2 = *r2;
+    b = b2 > b ? b2 : b;                                       // non-negative floats order like their bit patterns
+  }
+  if (b != 0u && b < 0x7f800000u) {
+    int ex;
+    frexpf(__uint_as_float(b), &ex);                           // bound in [2^(ex-1), 2^ex)
+    int T = 11 - ex;
+    T = T < -126 ? -126 : (T > 126 ? 126 : T);
+    xs = ldexpf(1.0f, T);
+    ixs = ldexpf(1.0f, -T);
+  }
+}
+// one float4 -> (fp16(v xs), fp16((v xs - fp16(v xs)) 2^11)) as two packed register pairs: v_fma_mixlo/hi_f16 multiply, round and pack in
+// one instruction, v_fma_mix_f32 forms v xs - (float)h exactly (the product is exact, the difference representable): 12 vector
+// instructions per float4 (the compiler's cast / convert / subtract / multiply / pack sequence: 19)
+__device__ __forceinline__ void x3_split4(const f32x4 v, float xs, unsigned (&h)[2], unsigned (&l)[2]) {
+  const float k2048 = 2048.0f;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float t0, t1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[p]) : "v"(v[2 * p]), "s"(xs));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[p]) : "v"(v[2 * p + 1]), "s"(xs));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(t0) : "v"(v[2 * p]), "s"(xs), "v"(h[p]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(t1) : "v"(v[2 * p + 1]), "s"(xs), "v"(h[p]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l[p]) : "v"(t0), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[p]) : "v"(t1), "s"(k2048));
+  }
+}
+// max |y| of a wave -> the range slot: one no-return atomicMax per wave, and only when the wave's maximum exceeds what the slot already
+// holds (an agent-scope load: atomics execute at the memory side) -- after the first round of blocks almost no wave issues one
+__device__ __forceinline__ void x3_range_out(unsigned* slot, float m, int lane) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) {
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -85,11 +139,11 @@ __host__ __device__ inline int f4(int row) { return (-(row >> 2)) & 3; }      //
 __host__ __device__ inline int sx(int col) { return ((col >> 2) & 1) * 2; }
 __device__ __forceinline__ int pcol(int fi) { return fi < 4 ? fi : (fi >= 12 ? fi - 8 : fi + 4); }
 
-// RS = true: the input is multiplied by the power of two that brings max |x| (hdr[2], device-resident, written by
-// shdr_conv2d_x3_input_absmax_f32) to [2^10, 2^11) before the split and the result divided by it -- both exact.  For inputs far below
-// the fp16 range: the output gradients dz of the training steps (max |dz| 3e-8 ... 2e-2 in the joint step: unscaled, their high terms
-// are fp16 subnormals and the parameter gradient differed from the exact-fp32 kernels' by 3e-5; scaled, by the run-to-run noise).
-template <bool UP, int KH, int KW, bool RS = false>
+// The input is multiplied by the power of two that brings its range bound (a.xr1 / a.xr2) to [2^10, 2^11) before the split and the result
+// divided by it -- both exact.  This matters at both ends: activations beyond the fp16 range, and the output gradients dz of the
+// training steps far below it (max |dz| 3e-8 ... 2e-2 in the joint step: unscaled, their high terms are fp16 subnormals and the
+// parameter gradient differed from the exact-fp32 kernels' by 3e-5; scaled, by the run-to-run noise).
+template <bool UP, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   using G = X3G<KH, KW>;
   constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, PATCH_HALVES = G::PATCH_HALVES, NTAPS = KH * KW;
@@ -154,28 +208,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     for (int j = 0; j < LRJ; ++j)
       if (tid + 256 * j < LRPIX * 8) *reinterpret_cast<f32x4*>(lrs + 4 * (tid + 256 * j)) = pr[j];
   };
-  float xs = 1.0f, ixs = 1.0f;                                 // RS: input scale 2^T and its inverse
-  if (RS) {
-    const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(a.hdr)[2]);
-    if (mx > 0.0f) {
-      int ex;
-      frexpf(mx, &ex);                                         // mx in [2^(ex-1), 2^ex)
-      int T = 11 - ex;
-      T = T < -100 ? -100 : (T > 100 ? 100 : T);
-      xs = ldexpf(1.0f, T);
-      ixs = ldexpf(1.0f, -T);
-    }
-  }
+  float xs, ixs;                                               // input scale 2^T and its inverse
+  x3_range_scale(a.xr1, a.xr2, xs, ixs);
   auto split_store = [&](int dst, const f32x4 v4) __attribute__((always_inline)) {            // one float4 -> 8 bytes in each fp16 image
-    f16x4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float v = RS ? v4[e] * xs : v4[e];
-      h[e] = (_Float16)v;
-      l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
-    }
-    *reinterpret_cast<f16x4*>(patch_h + dst) = h;
-    *reinterpret_cast<f16x4*>(patch_l + dst) = l;
+    unsigned h[2], l[2];
+    x3_split4(v4, xs, h, l);
+    *reinterpret_cast<uint2*>(patch_h + dst) = make_uint2(h[0], h[1]);
+    *reinterpret_cast<uint2*>(patch_l + dst) = make_uint2(l[0], l[1]);
   };
   auto expand_store = [&]() __attribute__((always_inline)) {   // UP: scratch -> up-sampled 18 x 18 patch (the arithmetic of resize2x_kernel) -> images
     // the geometry of a piece is recomputed per chunk (a few integer operations) instead of being held in 22 registers: the
@@ -363,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
   }
+  float ym = 0.0f;                                             // max |y| over this lane's stored values (a.yr)
 #pragma unroll
   for (int mp = 0; mp < MT / 2; ++mp) {
     const int oh = oh0 + wave * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
@@ -388,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
         if (a.y && oh + r < a.H && ow < a.W)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
+        if (a.yr && oh + r < a.H) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[r][0]), fabsf(v[r][1]))), fmaxf(fabsf(v[r][2]), fabsf(v[r][3])));
       }
       if (a.yp && a.final) {
         f32x4 m;
@@ -406,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       }
     }
   }
+  if (a.yr && a.final) x3_range_out(a.yr, ow < a.W ? ym : 0.0f, lane);      // (a pooled output is bounded by the same maximum)
 }
 
 #undef patch_h
@@ -486,19 +528,19 @@ int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
 }
 inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * Cout; }    // two fp16 images
 
-template <bool UP, int KH, int KW, bool RS = false>
+template <bool UP, int KH, int KW>
 int launch_x3(const X3Args& a, hipStream_t st) {
   constexpr int lds = UP ? X3G<KH, KW>::LDS_BYTES_UP : X3G<KH, KW>::LDS_BYTES;
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW, RS>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_x3_kernel");
 }
 
@@ -509,12 +551,12 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv != d->Cout || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
-  if (getenv("SHDR_NO_X3")) return 0;
+  if (SHDR_ENV("SHDR_NO_X3")) return 0;
   if (d->stride == 1) {
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad_t == 1 && d->pad_l == 1;
     // 1 x 1 layers (the skip layers of hallucination_net.py:93-107 on tf.concat of two sources, the bottleneck convs of the ResNet
     // blocks): one tap per chunk, so the patch split is not amortised over nine taps -- still 2-3x the fp32-MFMA kernel from K = 256 on
-    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && getenv("SHDR_NO_X3_1X1") == nullptr;
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && SHDR_ENV("SHDR_NO_X3_1X1") == nullptr;
     if (!(k3 || k1) || d->Ho != d->H || d->Wo != d->W) return 0;
   } else {
     // the 7 x 7 / stride-2 stem with TF SAME padding (one source, no prologue)
@@ -522,13 +564,13 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
     shdr_same_pad(d->H, 7, 2, &ho, &pt);
     shdr_same_pad(d->W, 7, 2, &wo, &pl);
     if (d->stride != 2 || d->KH != 7 || d->KW != 7 || d->C2 != 0 || d->prologue != SHDR_PROLOGUE_NONE || d->Ho != ho || d->Wo != wo || d->pad_t != pt ||
-        d->pad_l != pl || getenv("SHDR_NO_X3_STRIDE2"))
+        d->pad_l != pl || SHDR_ENV("SHDR_NO_X3_STRIDE2"))
       return 0;
   }
   // enough blocks to fill the chip: the deepest, smallest maps stay on the fused Winograd kernel (8 x 16 tiles)
   const long blocks = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 64);
   long min_blocks = 192;          // measured (tools/dbg/x3_threshold.py): 256 blocks 1.24-1.28x the fused Winograd kernel, 128 blocks 0.75x
-  if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
+  if (const char* e = SHDR_ENV("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
   return blocks >= min_blocks ? 1 : 0;
 }
 
@@ -566,30 +608,45 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
   return shdr::check_launch("conv2d_x3_prepare_filter");
 }
 
+// max |x| of a tensor, atomicMax-ed into a RANGE SLOT (a device word holding the bit pattern of a non-negative float; the caller zeroes
+// it, e.g. one memset over a slab of slots per step).  The slot feeds x1_range / x2_range of the ranged convolution calls.
+extern "C" int shdr_absmax_f32(const float* x, int64_t n, float* range, void* stream) {
+  SHDR_REQUIRE(x && range, SHDR_E_NULL, "absmax: null pointer");
+  SHDR_REQUIRE(n > 0, SHDR_E_SHAPE, "absmax: n must be positive");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned* slot = reinterpret_cast<unsigned*>(range);
+  const int64_t n4 = shdr::aligned16(x) ? n / 4 : 0;
+  if (n4 > 0) {
+    int grid = shdr::stream_grid(n4);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(x3_absmax_big_kernel, dim3(grid), dim3(256), 0, st, x, (long)n4, slot);
+  }
+  if (n - 4 * n4 > 0) hipLaunchKernelGGL(x3_absmax_kernel, dim3(n4 > 0 ? 1 : (shdr::stream_grid(n) < 64 ? shdr::stream_grid(n) : 64)), dim3(256), 0, st, x + 4 * n4, (long)(n - 4 * n4), slot);
+  return shdr::check_launch("absmax");
+}
+
+// the range slot inside a prepared filter's header (slot 2): the low-level protocol of desc.prologue = SHDR_PROLOGUE_RANGE_SCALE
 extern "C" int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float* prepared, void* stream) {
   SHDR_REQUIRE(x && prepared, SHDR_E_NULL, "conv2d_x3_input_absmax: null pointer");
   SHDR_REQUIRE(n > 0 && n % 4 == 0 && shdr::aligned16(x), SHDR_E_SHAPE, "conv2d_x3_input_absmax: n must be a positive multiple of 4, x 16-byte aligned");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int grid = shdr::stream_grid(n / 4);
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(x3_absmax_big_kernel, dim3(grid), dim3(256), 0, st, x, (long)(n / 4), reinterpret_cast<unsigned*>(prepared) + 2);
-  return shdr::check_launch("conv2d_x3_input_absmax");
+  return shdr_absmax_f32(x, n, prepared + 2, stream);
 }
 
-extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                      const float* scale, const float* shift, float* y, float* y_pool, void* stream) {
+extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                             const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
+                                             const float* x2_range, float* y_range, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or neither y nor y_pool");
   SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even Ho, Wo");
   const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X, rs = d->prologue == SHDR_PROLOGUE_RANGE_SCALE;
   SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || rs || (up && d->stride == 1 && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
                "conv2d_x3: the bilinear 2x prologue takes a stride-1 layer, one source and even (up-sampled) H, W");
-  SHDR_REQUIRE(!rs || (d->stride == 1 && d->KH == 3 && d->C2 == 0), SHDR_E_SHAPE, "conv2d_x3: the range-scale prologue is built for one-source 3x3 layers");
   SHDR_REQUIRE(shdr_conv2d_x3_ok_f32(d), SHDR_E_SHAPE, "conv2d_x3: layer shape not taken by this kernel");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_x3: x2 must be given iff C2 > 0");
   SHDR_REQUIRE((scale == nullptr) == (shift == nullptr), SHDR_E_NULL, "conv2d_x3: scale and shift come together");
   SHDR_REQUIRE(shdr::aligned16(x1) && (!x2 || shdr::aligned16(x2)) && shdr::aligned16(prepared) && (!y || shdr::aligned16(y)) &&
                    (!bias || shdr::aligned16(bias)) && (!scale || (shdr::aligned16(scale) && shdr::aligned16(shift))),
                SHDR_E_ALIGN, "conv2d_x3: tensors must be 16-byte aligned");
+  SHDR_REQUIRE(!x2 || ((x1_range == nullptr) == (x2_range == nullptr)), SHDR_E_NULL, "conv2d_x3: give the range of both sources or of neither");
   X3Args a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1;
   a.bias = bias; a.scale = scale; a.shift = shift; a.y = y; a.yp = y_pool;
@@ -602,6 +659,9 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
   a.nblk_m = a.N * a.tiles_x * a.tiles_y;
   a.nblk_n = a.Cout / 64;
   a.act1 = d->act1; a.act2 = d->act2;
+  a.xr1 = reinterpret_cast<const unsigned*>(x1_range);
+  a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);
+  a.yr = reinterpret_cast<unsigned*>(y_range);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
@@ -611,12 +671,12 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
   for (int i = 0; i < n; ++i) {
     a.hdr = pk;
     a.wp = reinterpret_cast<const _Float16*>(pk + X3_HEADER_FLOATS);
+    if (rs && !x1_range) a.xr1 = reinterpret_cast<const unsigned*>(pk) + 2;      // the header-slot protocol (shdr_conv2d_x3_input_absmax_f32)
     a.in_s = ph[i].step; a.bh = ph[i].bh; a.bw = ph[i].bw;
     a.yin = i > 0 ? y : nullptr;
     a.final = i == n - 1;
     int rc;
-    if (ph[i].th == 3 && ph[i].tw == 3 && rs) rc = launch_x3<false, 3, 3, true>(a, st);
-    else if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
+    if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
     else if (ph[i].th == 1 && ph[i].tw == 1) rc = launch_x3<false, 1, 1>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 4) rc = launch_x3<false, 4, 4>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 3) rc = launch_x3<false, 4, 3>(a, st);
@@ -626,4 +686,12 @@ extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1
     pk += x3_phase_floats(ph[i], Ct, d->Cout);
   }
   return SHDR_OK;
+}
+
+// The low-level entry point without range slots: the input is split as it stands (|x| must stay inside the fp16 range) unless
+// desc.prologue = SHDR_PROLOGUE_RANGE_SCALE names the header slot written by shdr_conv2d_x3_input_absmax_f32.  Hosts go through
+// shdr_conv2d_fwd_prepared_f32 / _ranged_f32, which never run a split-operand launch without a range.
+extern "C" int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                      const float* scale, const float* shift, float* y, float* y_pool, void* stream) {
+  return shdr_conv2d_fwd_x3_ranged_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, nullptr, nullptr, nullptr, stream);
 }

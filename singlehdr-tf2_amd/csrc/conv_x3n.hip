@@ -39,8 +39,50 @@ struct X3nArgs {
   float* yp;               // [N,H/2,W/2,COUT] = 2x2 pooled y (or null): needs even H, W and cout_valid == COUT
   int pool_avg;            // AveragePooling2D(2) instead of MaxPool2D(2)
   int N, H, W, C1, tiles_x, tiles_y, ntiles, act1, act2, cout_valid, res_cs;
-  int rs;                  // range scale: multiply the input by the power of two that brings hdr[2] = max |x| to [2^10, 2^11) (output gradients)
+  const unsigned* xr1;     // range slots of the sources (bits of an upper bound of max |x|, conv_x3.hip "Range"; null: no scaling)
+  const unsigned* xr2;
+  unsigned* yr;            // range slot of the output: atomicMax of max |y| (null: not wanted)
 };
+
+// conv_x3.hip: x3_range_scale / x3_split4 / x3_range_out (the same arithmetic; kept per translation unit)
+__device__ __forceinline__ void xn_range_scale(const unsigned* r1, const unsigned* r2, float& xs, float& ixs) {
+  xs = 1.0f;
+  ixs = 1.0f;
+  unsigned b = r1 ? *r1 : 0u;
+  if (r2) {
+    const unsigned b2 = *r2;
+    b = b2 > b ? b2 : b;
+  }
+  if (b != 0u && b < 0x7f800000u) {
+    int ex;
+    frexpf(__uint_as_float(b), &ex);
+    int T = 11 - ex;
+    T = T < -126 ? -126 : (T > 126 ? 126 : T);
+    xs = ldexpf(1.0f, T);
+    ixs = ldexpf(1.0f, -T);
+  }
+}
+__device__ __forceinline__ void xn_split4(const f32x4 v, float xs, unsigned (&h)[2], unsigned (&l)[2]) {
+  const float k2048 = 2048.0f;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float t0, t1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[p]) : "v"(v[2 * p]), "s"(xs));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[p]) : "v"(v[2 * p + 1]), "s"(xs));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(t0) : "v"(v[2 * p]), "s"(xs), "v"(h[p]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(t1) : "v"(v[2 * p + 1]), "s"(xs), "v"(h[p]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l[p]) : "v"(t0), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[p]) : "v"(t1), "s"(k2048));
+  }
+}
+__device__ __forceinline__ void xn_range_out(unsigned* slot, float m, int lane) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) {
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
+}
 
 __host__ __device__ inline int pswz(int row) { return (-(row >> 2)) & 3; }
 
@@ -109,18 +151,8 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       pch[j] = (ok && 4 * c4 < a.C1) ? 4 * c4 : -1;            // channels beyond the source's (3 -> 4, 9 -> 12 padded inputs) are zero
     }
   }
-  float xs = 1.0f, ixs = 1.0f;                                 // rs: input scale 2^T and its inverse (conv_x3.hip, SHDR_PROLOGUE_RANGE_SCALE)
-  if (a.rs) {
-    const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(a.hdr)[2]);
-    if (mx > 0.0f) {
-      int ex;
-      frexpf(mx, &ex);
-      int T = 11 - ex;
-      T = T < -100 ? -100 : (T > 100 ? 100 : T);
-      xs = ldexpf(1.0f, T);
-      ixs = ldexpf(1.0f, -T);
-    }
-  }
+  float xs, ixs;                                               // input scale 2^T and its inverse (conv_x3.hip "Range")
+  xn_range_scale(a.xr1, a.xr2, xs, ixs);
   f32x4 pr[G::PJ];
   // the 7x7 image layers (4 -> 16: four stores per tile and a long tap loop) measured 0.157 ms with compiler-scheduled loads against
   // 0.205 with the asm loads + counted wait that help every other shape: they keep the plain loads
@@ -166,15 +198,10 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
 #pragma unroll
     for (int j = 0; j < G::PJ; ++j) {
       if (pdst[j] < 0) continue;
-      f16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = a.rs ? pr[j][e] * xs : pr[j][e];       // uniform branch
-        h[e] = (_Float16)v;
-        l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
-      }
-      *reinterpret_cast<f16x4*>(patch_h + pdst[j]) = h;
-      *reinterpret_cast<f16x4*>(patch_l + pdst[j]) = l;
+      unsigned h[2], l[2];
+      xn_split4(pr[j], xs, h, l);
+      *reinterpret_cast<uint2*>(patch_h + pdst[j]) = make_uint2(h[0], h[1]);
+      *reinterpret_cast<uint2*>(patch_l + pdst[j]) = make_uint2(l[0], l[1]);
     }
   };
 
@@ -209,6 +236,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
     bias_r[ni] = (a.bias && a.cout_valid == G::COUT) ? *reinterpret_cast<const f32x4*>(a.bias + ni * 16 + 4 * fg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ym = 0.0f;                                             // max |y| over the values this lane stores (a.yr)
   int tile = blockIdx.x;
   if (tile < a.ntiles) load_patch(tile);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the filter (LDS-DMA) have landed
@@ -299,6 +327,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
           // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
           *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
+          if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           acc[mi][ni] = v;                                            // kept for the pooled output below
         } else {
 #pragma unroll
@@ -307,7 +336,9 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
               float t = shdr::act_apply(v[e] + (a.bias ? a.bias[co + e] : 0.f), a.act1);
               if (a.scale) t = t * a.scale[co + e] + a.shift[co + e];
               if (a.res) t += a.res[pix * a.res_cs + co + e];
-              a.y[pix * a.cout_valid + co + e] = shdr::act_apply(t, a.act2);
+              t = shdr::act_apply(t, a.act2);
+              a.y[pix * a.cout_valid + co + e] = t;
+              if (a.yr) ym = fmaxf(ym, fabsf(t));
             }
         }
       }
@@ -339,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       }
     }
   }
+  if (a.yr) xn_range_out(a.yr, ym, lane);                         // once per persistent block and wave (a pooled output has the same bound)
 #undef filt_h
 #undef filt_l
 #undef patch_h
@@ -425,19 +457,19 @@ extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
   // (desc.prologue plays no part: the plan of a layer must not depend on it -- shdr_conv2d_fwd_prepared_f32 materialises a prologue this
   //  kernel does not fuse and re-enters with the same prepared filter)
   // Cout 64: the 3x3 image layers (3 -> 4 channels in, hal conv1_1 / VGG conv1_1: K = 36, an HBM-write-bound layer)
-  const bool image64 = d->Cout == 64 && d->KH == 3 && d->C2 == 0 && d->C1 <= 8 && getenv("SHDR_NO_X3N_IMAGE64") == nullptr;
+  const bool image64 = d->Cout == 64 && d->KH == 3 && d->C2 == 0 && d->C1 <= 8 && SHDR_ENV("SHDR_NO_X3N_IMAGE64") == nullptr;
   if (!(d->Cout == 16 || d->Cout == 32 || image64) || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv > d->Cout || (d->y_cstride != 0 && d->y_cstride != cv)) return 0;
   const bool one = d->C2 == 0 && d->C1 % 4 == 0 && d->C1 >= 4 && d->C1 <= 32, two = d->C1 == 16 && d->C2 == 16;
-  if (!(one || two) || getenv("SHDR_NO_X3") || getenv("SHDR_NO_X3N")) return 0;
+  if (!(one || two) || SHDR_ENV("SHDR_NO_X3") || SHDR_ENV("SHDR_NO_X3N")) return 0;
   if ((long)d->N * d->H * d->W * 32 >= (1L << 31)) return 0;
   const int ct = ct_of(d);
   const long filt = 2L * ((d->KH * d->KW * ct + 31) / 32) * d->Cout * 64;
   const long patch = 2L * (16 + d->KH - 1) * (16 + d->KW - 1) * ct * 2;
   if (filt + patch > 150 * 1024) return 0;
   long min_tiles = 256;                                     // persistent blocks: at least one tile per CU
-  if (const char* e = getenv("SHDR_X3_MIN_BLOCKS")) min_tiles = atol(e);
+  if (const char* e = SHDR_ENV("SHDR_X3_MIN_BLOCKS")) min_tiles = atol(e);
   return (long)d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16) >= min_tiles ? 1 : 0;
 }
 
@@ -465,8 +497,9 @@ extern "C" int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, con
   return shdr::check_launch("conv2d_x3n_prepare_filter");
 }
 
-extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                       const float* scale, const float* shift, const float* residual, float* y, float* y_pool, void* stream) {
+extern "C" int shdr_conv2d_fwd_x3n_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                              const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
+                                              const float* x1_range, const float* x2_range, float* y_range, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && y, SHDR_E_NULL, "conv2d_x3n: null desc/x1/filter/y");
   SHDR_REQUIRE(!y_pool || (d->H % 2 == 0 && d->W % 2 == 0 && shdr::aligned16(y_pool) && (d->cout_valid == 0 || d->cout_valid == d->Cout)),
                SHDR_E_SHAPE, "conv2d_x3n: the pooled output needs even H, W and every filter column stored");
@@ -487,7 +520,11 @@ extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x
   a.tiles_y = (d->H + 15) / 16;
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   a.act1 = d->act1; a.act2 = d->act2;
-  a.rs = d->prologue == SHDR_PROLOGUE_RANGE_SCALE;
+  SHDR_REQUIRE(!x2 || ((x1_range == nullptr) == (x2_range == nullptr)), SHDR_E_NULL, "conv2d_x3n: give the range of both sources or of neither");
+  a.xr1 = reinterpret_cast<const unsigned*>(x1_range);
+  a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);
+  if (!x1_range && d->prologue == SHDR_PROLOGUE_RANGE_SCALE) a.xr1 = reinterpret_cast<const unsigned*>(prepared) + 2;   // header-slot protocol
+  a.yr = reinterpret_cast<unsigned*>(y_range);
   a.cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   a.res_cs = d->res_cstride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -500,4 +537,10 @@ extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x
   if (d->KH == 3) return dispatch_ct<3, 2>(a, d, st);
   if (d->KH == 5) return dispatch_ct<5, 2>(a, d, st);
   return dispatch_ct<7, 2>(a, d, st);
+}
+
+// the low-level entry point without range slots (conv_x3.hip: shdr_conv2d_fwd_x3_f32)
+extern "C" int shdr_conv2d_fwd_x3n_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                       const float* scale, const float* shift, const float* residual, float* y, float* y_pool, void* stream) {
+  return shdr_conv2d_fwd_x3n_ranged_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, y_pool, nullptr, nullptr, nullptr, stream);
 }

@@ -275,7 +275,7 @@ extern "C" int shdr_soft_hist_fwd_f32(const float* x, float* y, int64_t npix, in
     int g = Q, h = 256;
     while (h) { const int r = g % h; g = h; h = r; }
     const long unit = Q / g;
-    if (unit <= 64 && getenv("SHDR_FRONTEND_QUADS") == nullptr) {
+    if (unit <= 64 && SHDR_ENV("SHDR_FRONTEND_QUADS") == nullptr) {
       long grid = shdr::stream_grid(total);
       grid = (grid + unit - 1) / unit * unit;
       hipLaunchKernelGGL(soft_hist_rows_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, y, (long)npix, C, B, thr);
@@ -300,7 +300,7 @@ extern "C" int shdr_lin_frontend_fwd_f32(const float* img, float* y, int N, int 
   SHDR_REQUIRE(y_channels == 93 || y_channels == 96, SHDR_E_SHAPE, "lin_frontend: y_channels must be 93 or 96");
   SHDR_REQUIRE((long)N * H <= 65535, SHDR_E_SHAPE, "lin_frontend: N*H must be <= 65535");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (getenv("SHDR_FRONTEND_QUADS") != nullptr) {          // the per-quad kernel (kept for comparison)
+  if (SHDR_ENV("SHDR_FRONTEND_QUADS") != nullptr) {          // the per-quad kernel (kept for comparison)
     const dim3 grid((unsigned)((W * 24 + 255) / 256), (unsigned)(N * H));
     if (y_channels == 96) hipLaunchKernelGGL(lin_frontend_kernel<96>, grid, dim3(256), 0, st, img, y, N, H, W);
     else hipLaunchKernelGGL(lin_frontend_kernel<93>, grid, dim3(256), 0, st, img, y, N, H, W);

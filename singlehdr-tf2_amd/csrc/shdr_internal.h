@@ -41,6 +41,24 @@ inline int device_slot() {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// SHDR_* environment switches (kernel-family opt-outs, tile experiments, thresholds) are read ONCE per call site and process, not on
+// every launch -- a conv launch used to walk the environment up to ten times.  shdr_config_reload() (include/shdr.h) invalidates every
+// cached value: call it after changing a switch inside a running process (the tests do).
+extern int g_env_epoch;
+struct EnvSlot {
+  int epoch = -1;
+  const char* value = nullptr;
+};
+inline const char* env_cached(EnvSlot& slot, const char* name) {
+  const int e = __atomic_load_n(&g_env_epoch, __ATOMIC_ACQUIRE);
+  if (slot.epoch != e) {                         // (two threads racing here store the same two words)
+    slot.value = getenv(name);
+    slot.epoch = e;
+  }
+  return slot.value;
+}
+#define SHDR_ENV(name) ([]() -> const char* { static ::shdr::EnvSlot slot; return ::shdr::env_cached(slot, name); }())
+
 #define SHDR_REQUIRE(cond, code, ...) \
   do {                                \
     if (!(cond)) return ::shdr::fail((code), __VA_ARGS__); \
@@ -68,7 +86,7 @@ inline long block_slots(KernelT kernel, int threads, size_t lds) {
 // slices (of `units` work items, at least `min_slice` each) per tile so that tiles x slices fills `rounds` rounds of the slots
 inline long slice_for_rounds(long slots, long tiles, long units, long min_slice) {
   long rounds = 1;
-  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
+  if (const char* e = SHDR_ENV("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
   long ns = slots * rounds / tiles;
   if (ns < 1) ns = 1;
   long slice = (units + ns - 1) / ns;

@@ -467,7 +467,7 @@ int launch_wgrad_prec(WgradArgs& a, hipStream_t st) {
   // pixel slices: one round of the chip's block slots, at least 1024 pixels per slice to bound the atomics
   const long tiles = (long)a.KH * a.KW * a.tiles_m * a.tiles_n;
   long slice = shdr::slice_for_rounds(slots_of[dev_slot], tiles, a.npix, 1024);
-  if (getenv("SHDR_WGRAD_LEGACY_GRID")) {
+  if (SHDR_ENV("SHDR_WGRAD_LEGACY_GRID")) {
     const long want = (256L * 8 + tiles - 1) / tiles;
     slice = (a.npix + want - 1) / want;
     if (slice < 2048) slice = 2048;
@@ -537,14 +537,14 @@ extern "C" int shdr_conv2d_wgrad_f32(const shdr_conv2d_desc* d, const float* x, 
   if (mfma_ok && auto_algo && a.stride == 1 && (a.Cx == 16 || a.Cx == 32) &&
       (a.Cout == 16 || a.Cout == 32) && a.KH == a.KW && (a.KH == 3 || a.KH == 5 || a.KH == 7) && a.Ho == a.H && a.Wo == a.W &&
       (a.KH == 3 || (a.KH == 5 && a.Cx * a.Cout <= 512) || (a.KH == 7 && a.Cx == 16 && a.Cout == 16)) &&   // <= 256 VGPRs
-      getenv("SHDR_NO_ALLTAPS") == nullptr) {
+      SHDR_ENV("SHDR_NO_ALLTAPS") == nullptr) {
     if (a.Cx == 16) return a.Cout == 16 ? dispatch_alltaps<1, 1>(a, st) : dispatch_alltaps<1, 2>(a, st);
     return a.Cout == 16 ? dispatch_alltaps<2, 1>(a, st) : dispatch_alltaps<2, 2>(a, st);
   }
   if (mfma_ok && d->algo != SHDR_ALGO_DIRECT) {
     if (a.Cx % 128 == 0) return dispatch_n<128>(a, st);
     if (a.Cx % 64 == 0) return dispatch_n<64>(a, st);
-    if (a.Cx % 96 == 0 && a.Cout % 32 == 0 && getenv("SHDR_NO_WGRAD96") == nullptr) return dispatch_n96(a, st);
+    if (a.Cx % 96 == 0 && a.Cout % 32 == 0 && SHDR_ENV("SHDR_NO_WGRAD96") == nullptr) return dispatch_n96(a, st);
     if (a.Cx % 32 == 0) return dispatch_n<32>(a, st);
     return dispatch_n<16>(a, st);
   }

@@ -290,7 +290,7 @@ int launch_wgrad_f16(WgradHArgs& a, hipStream_t st) {
   }
   const long slots = slots_of[dev_slot];
   int rounds = 1;
-  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atoi(e);
+  if (const char* e = SHDR_ENV("SHDR_WGRAD_ROUNDS")) rounds = atoi(e);
   long slice = a.npix;
   bool chosen = false;
   for (int r = 1; r <= 64 && !(chosen && r > rounds); ++r) {
@@ -340,7 +340,7 @@ extern "C" int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, i
                "wgrad_f16: tensor too large");
   SHDR_REQUIRE(shdr::aligned16(x) && shdr::aligned16(dz), SHDR_E_ALIGN, "wgrad_f16: tensors must be 16-byte aligned");
   // stride-1 layers with many pixels: every tap from one staged strip (wgrad_f16_alltaps.hip)
-  if (shdr_conv2d_wgrad_alltaps_ok_f16(d, which, dz_channels) && getenv("SHDR_NO_ALLTAPS") == nullptr)
+  if (shdr_conv2d_wgrad_alltaps_ok_f16(d, which, dz_channels) && SHDR_ENV("SHDR_NO_ALLTAPS") == nullptr)
     return shdr_conv2d_wgrad_alltaps_f16(d, x, which, dz, dz_channels, c1_rows, c2_rows, dw, stream);
   WgradHArgs a{};
   a.x = reinterpret_cast<const _Float16*>(x);
@@ -357,8 +357,8 @@ extern "C" int shdr_conv2d_wgrad_f16(const shdr_conv2d_desc* d, const void* x, i
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // 256-wide tiles (8 waves, one block per CU) halve the L2 -> LDS traffic per flop of the widest layers
   long min256 = 4096;
-  if (const char* e = getenv("SHDR_WGRAD_256_MIN_PIXELS")) min256 = atol(e);
-  if (getenv("SHDR_NO_WGRAD_256") == nullptr && a.npix >= min256) {
+  if (const char* e = SHDR_ENV("SHDR_WGRAD_256_MIN_PIXELS")) min256 = atol(e);
+  if (SHDR_ENV("SHDR_NO_WGRAD_256") == nullptr && a.npix >= min256) {
     const bool one = a.KH * a.KW == 1;                           // 1x1: few pixels per block, only the widest pay (0.128 -> 0.115 ms at 1024 -> 512)
     if (Cx % 256 == 0 && a.Cz % 256 == 0) return launch_wgrad_f16<256, 256, 8, 4>(a, st);
     if (Cx % 256 == 0 && a.Cz % 128 == 0 && !one) return launch_wgrad_f16<256, 128, 8, 4>(a, st);

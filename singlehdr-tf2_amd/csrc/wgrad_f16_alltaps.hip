@@ -334,7 +334,7 @@ int launch_alltaps(WgradAArgs& a, hipStream_t st) {
     slots_of[dev_slot] = (long)cus * occ;
   }
   long rounds = 1;
-  if (const char* e = getenv("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
+  if (const char* e = SHDR_ENV("SHDR_WGRAD_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
   long want = slots_of[dev_slot] * rounds / tiles;
   if (want < 1) want = 1;
   long slice = (a.nsegs + want - 1) / want;
@@ -354,7 +354,7 @@ extern "C" int shdr_conv2d_wgrad_alltaps_ok_f16(const shdr_conv2d_desc* d, int w
   if (d->pad_t != (d->KH - 1) / 2 || d->pad_l != (d->KW - 1) / 2 || d->Ho != d->H || d->Wo != d->W) return 0;
   const int cx = which ? d->C2 : d->C1;
   long min_pixels = 65536;                                            // few pixels: the per-tap kernel with its larger tiles
-  if (const char* e = getenv("SHDR_ALLTAPS_MIN_PIXELS")) min_pixels = atol(e);
+  if (const char* e = SHDR_ENV("SHDR_ALLTAPS_MIN_PIXELS")) min_pixels = atol(e);
   if ((long)d->N * d->H * d->W < min_pixels) return 0;
   if (d->KH == 3) return ((cx == 8 || cx == 16 || cx == 32 || cx % 64 == 0) && cx <= 128 && (dz_channels == 8 || dz_channels == 16 || dz_channels == 32 || dz_channels == 64)) ? 1 : 0;
   if (d->KH == 5) return ((cx == 16 || cx == 32) && (dz_channels == 16 || dz_channels == 32)) ? 1 : 0;

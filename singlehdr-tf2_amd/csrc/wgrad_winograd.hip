@@ -267,7 +267,7 @@ extern "C" int shdr_conv2d_wgrad_winograd_f32(const float* x, const float* dz, f
   // unit slices: one round of the chip's block slots, >= 32 units (256 tiles) per block to bound the atomics
   const long tiles = (long)a.tiles_m * a.tiles_n;
   long slice = shdr::slice_for_rounds(slots_of[dev_slot], tiles, a.units, 32);
-  if (getenv("SHDR_WGRAD_LEGACY_GRID")) {
+  if (SHDR_ENV("SHDR_WGRAD_LEGACY_GRID")) {
     const long want = (768 + tiles - 1) / tiles;
     slice = (a.units + want - 1) / want;
     if (slice < 32) slice = 32;

@@ -466,7 +466,7 @@ extern "C" int shdr_conv2d_winograd_fused2_f32(const float* x, const float* x2, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // The 16 x 16 tile (one block per CU, half the filter bytes per MFMA) was measured equal on wide layers and 5..10 % slower on
   // narrow ones (the kernel is not bound by the filter stream): it stays selectable for experiments only.
-  const char* force = getenv("SHDR_WINOGRAD_TILE");        // "16": the tall tile
+  const char* force = SHDR_ENV("SHDR_WINOGRAD_TILE");        // "16": the tall tile
   return (force && force[0] == '1') ? launch_fused<2>(a, st) : launch_fused<1>(a, st);
 }
 

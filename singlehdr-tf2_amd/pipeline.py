@@ -45,6 +45,10 @@ class Inference:
             return torch.cat(outs, dim=0)
 
     def _run(self, ldr, return_intermediates):
+        with K.range_scope():              # one zeroed slab of range slots per forward and stream (K: "range slots")
+            return self._run_scoped(ldr, return_intermediates)
+
+    def _run_scoped(self, ldr, return_intermediates):
         pred_deq = self._deq(ldr, training=False)
         C_pred = K.clip(pred_deq, 0.0, 1.0)
         pred_invcrf = self._lin(C_pred, training=False)
@@ -135,6 +139,10 @@ class FlatParams:
                 v.data = self.flat[o:o + k].view(v.shape)       # the variable now aliases the flat buffer
                 v.grad = self.grad[o:o + k].view(v.shape)       # autograd accumulates in place
                 v._shdr_accum = True                            # ...and the backward kernels add into it directly (_autograd._acc)
+        # Contract of `_shdr_accum` (_autograd._acc): the backward kernels ADD each parameter gradient into its slice of `self.grad`
+        # and return None to autograd.  So (1) backward only with a zeroed flat gradient (`zero_grad()` at the top of every step),
+        # (2) `torch.autograd.grad(...)` / a plain `.backward()` on these variables returns None for them and still adds into the flat
+        # buffer, (3) whoever reads `self.grad` after `backward()` first joins every stream a forward op ran on (`_join_streams`).
         self.numel = n                                          # padded length of the flat buffers
         self.num_params = sum(v.numel() for v in self.variables)
 
@@ -212,19 +220,19 @@ class JointTrainStep:
         for st in streams:
             st.wait_stream(main)
 
-        with torch.cuda.stream(streams[0]):   # Dequantization (:150-153)
+        with torch.cuda.stream(streams[0]), K.range_scope():   # Dequantization (:150-153)
             pred_deq = self._deq(jpeg_img_float, training=True)
             C_pred = K.clip(pred_deq, 0.0, 1.0)
             loss_deq = K.diff_loss(C_pred, ldr, 0) * mask
 
-        with torch.cuda.stream(streams[1]):   # Linearization (:156-160)
+        with torch.cuda.stream(streams[1]), K.range_scope():   # Linearization (:156-160)
             pred_invcrf = self._lin(ldr, training=True)
             B_pred = tf_utils.apply_rf(ldr, pred_invcrf)
             crf_loss = K.diff_loss(pred_invcrf, invcrf, 0)                         # [b] here, [b,1] in the reference
             l2_lin = K.diff_loss(B_pred, clipped_hdr_t, 0)
             loss_lin = _broadcast_lin_loss(10.0 * l2_lin, crf_loss, mask)            # [b,1,b,1]
 
-        with torch.cuda.stream(streams[2]):   # Hallucination (:163-182)
+        with torch.cuda.stream(streams[2]), K.range_scope():   # Hallucination (:163-182)
             alpha = K.alpha_mask(clipped_hdr_t, thr)
             bgr_pred_hal = self._hal(clipped_hdr_t, training=True)
             A_pred = K.blend_const(clipped_hdr_t, alpha, bgr_pred_hal, thr)      # clipped + alpha * bgr2rgb(hal)
@@ -250,10 +258,20 @@ class JointTrainStep:
         return dict(total=total_loss, objective=objective, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
                     crf_loss=crf_loss, C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)
 
+    def _join_streams(self):
+        """The backward kernels add parameter gradients straight into the flat gradient buffer on the stream of their forward op
+        (FlatParams: `_shdr_accum`) and hand autograd no tensor for them, so autograd's own producer -> AccumulateGrad stream
+        hand-off does not cover those writes: the collective and the optimizer wait for the three side streams explicitly."""
+        if self._streams is not None:
+            main = torch.cuda.current_stream()
+            for st in self._streams:
+                main.wait_stream(st)
+
     def __call__(self, ds, invcrf, apply=True):
         self.params.zero_grad()
         out = self.losses(ds, invcrf)
         out["objective"].backward()                       # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
+        self._join_streams()
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)   # the ONE gradient collective
@@ -330,7 +348,8 @@ class TrainStep:
     def __call__(self, ds, apply=True):
         self.params.zero_grad()
         self._objective = None
-        loss, outputs = self.forward(ds)
+        with K.range_scope():
+            loss, outputs = self.forward(ds)
         # tape.gradient of a non-scalar loss = gradient of its sum (for `lin` the sum over the broadcast [b,1,b,1] tensor)
         (loss.sum() if self._objective is None else self._objective).backward()
         if self.pg is not None and self.world > 1:
@@ -387,7 +406,7 @@ class FinetuneStep:
 
     def __call__(self, ldr, hdr, apply=True):
         self.params.zero_grad()
-        with K.precision(self.precision):
+        with K.precision(self.precision), K.range_scope():
             out = self.forward(ldr, hdr)
             (out["loss_sum"].sum() * self.loss_scale).backward()
         if self.loss_scale != 1.0:

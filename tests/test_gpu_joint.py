@@ -51,7 +51,7 @@ def setup(shdr, emor_table):
     return dict(step=step, models=ms, batch=tuple(dev(t) for t in batch), inv=dev(inv), ref=ref, tP=tP, P=P)
 
 
-def test_joint_losses_match_reference(setup):
+def test_joint_losses_match_reference(setup, split_forced):
     out = setup["step"](setup["batch"], setup["inv"], apply=False)
     b = setup["batch"][0].shape[0]
     assert tuple(out["loss_lin"].shape) == (b, 1, b, 1) == tuple(out["total"].shape)     # the reference's broadcast (:158-160,183)
@@ -65,7 +65,7 @@ def test_joint_losses_match_reference(setup):
         assert rel_err(host(out[k]), setup["ref"][k].detach().numpy()) <= 1e-4, k
 
 
-def test_joint_gradients_and_flat_buffer(setup):
+def test_joint_gradients_and_flat_buffer(setup, split_forced):
     step = setup["step"]
     step(setup["batch"], setup["inv"], apply=False)
     assert step.params.num_params == 27741644                   # deq+lin+hal trainable parameters

@@ -44,7 +44,7 @@ def build(shdr, name, seed):
 
 
 @pytest.mark.parametrize("hw", [(64, 64), (32, 96)])
-def test_dequantization_net_parity(shdr, hw):
+def test_dequantization_net_parity(shdr, hw, split_forced):
     m, p = build(shdr, "deq", 21)
     x = quantised_image(np.random.default_rng(1), (2,) + hw + (3,))
     with torch.no_grad():                        # the inference path proper: fused epilogues (tanh + residual add in the last conv)
@@ -53,7 +53,7 @@ def test_dequantization_net_parity(shdr, hw):
     assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
 
 
-def test_refinement_net_parity(shdr):
+def test_refinement_net_parity(shdr, split_forced):
     m, p = build(shdr, "ref", 22)
     x = np.random.default_rng(2).random((1, 64, 64, 9))
     ref = nets.ref_forward(p, x)
@@ -65,7 +65,7 @@ def test_refinement_net_parity(shdr):
     assert y.requires_grad and rel_err(host(y), ref) <= TOL
 
 
-def test_hallucination_net_parity(shdr):
+def test_hallucination_net_parity(shdr, split_forced):
     m, p = build(shdr, "hal", 23)
     x = quantised_image(np.random.default_rng(3), (1, 64, 96, 3))
     with torch.no_grad():                        # fused folded-BN / relu epilogues, conv + max-pool pairs in one launch
@@ -74,7 +74,7 @@ def test_hallucination_net_parity(shdr):
     assert (y >= 0).all() and rel_err(y, ref) <= TOL
 
 
-def test_linearization_net_parity(shdr, emor_table):
+def test_linearization_net_parity(shdr, emor_table, split_forced):
     m, p = build(shdr, "lin", 24)
     x = quantised_image(np.random.default_rng(4), (2, 64, 64, 3))
     with torch.no_grad():                        # fused folded-BN / residual / relu epilogues
@@ -88,7 +88,7 @@ def test_linearization_net_parity(shdr, emor_table):
     np.testing.assert_array_equal(h, ops.histogram_layer(x.astype(np.float32), 8))
 
 
-def test_vgg16_parity(shdr):
+def test_vgg16_parity(shdr, split_forced):
     p = nets.init_params(nets.vgg_spec(), 25)
     dd = {n: [p[n + ".kernel"], p[n + ".bias"]] for n in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3")}
     v = shdr.vgg16.Vgg16(data_dict=dd)
@@ -100,7 +100,7 @@ def test_vgg16_parity(shdr):
     assert v.trainable_variables == []
 
 
-def test_inference_pipeline_matches_golden(shdr):
+def test_inference_pipeline_matches_golden(shdr, split_forced):
     g = np.load(os.path.join(GOLDEN, "inference_64.npz"))
     ms = {k: build(shdr, k, int(g["seed_" + k]))[0] for k in ("deq", "lin", "hal", "ref")}
     run = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
@@ -131,6 +131,28 @@ def test_graphed_inference_equals_eager(shdr):
     for _ in range(3):
         x = dev(quantised_image(rng, (1, 128, 96, 3)))
         np.testing.assert_array_equal(host(graphed(x)), host(eager(x)))
+
+
+def test_graph_replay_survives_another_shape_on_the_same_weights(shdr):
+    """A captured graph holds raw pointers of the prepared filters of ITS plans.  The same weight takes another plan at another input
+    shape (x3 needs >= 192 blocks): the prepared form of shape B must not evict shape A's (the cache on the filter
+    tensor is a dict per version now).  Replay A after eager AND graphed runs at B, compare with eager A."""
+    ms = {k: build(shdr, k, 60 + i)[0] for i, k in enumerate(("deq", "lin", "hal", "ref"))}
+    eager = shdr.pipeline.Inference(ms["deq"], ms["lin"], ms["hal"], ms["ref"])
+    graphed = shdr.pipeline.GraphedInference(ms["deq"], ms["lin"], ms["hal"], ms["ref"], copy_output=True)
+    K = shdr._ops
+    a_shape, b_shape = (1, 128, 96, 3), (4, 256, 256, 3)
+    assert K.conv2d_plan((1, 128, 96, 64), (3, 3, 64, 64)) != K.conv2d_plan((4, 256, 256, 64), (3, 3, 64, 64)) == "x3"
+    rng = np.random.default_rng(8)
+    xa, xb = dev(quantised_image(rng, a_shape)), dev(quantised_image(rng, b_shape))
+    want_a = host(eager(xa))
+    np.testing.assert_array_equal(host(graphed(xa)), want_a)            # capture A
+    want_b = host(eager(xb))                                            # eager B: prepares the x3 forms of the same weights
+    scratch = [torch.empty(1 << 20, device="cuda").normal_() for _ in range(8)]      # anything freed by B would be reused by now
+    np.testing.assert_array_equal(host(graphed(xa)), want_a)            # replay A
+    np.testing.assert_array_equal(host(graphed(xb)), want_b)            # capture B
+    np.testing.assert_array_equal(host(graphed(xa)), want_a)            # replay A again
+    del scratch
 
 
 def test_multi_stream_inference_equals_single_stream(shdr):

@@ -403,6 +403,100 @@ def test_conv2d_x3_split_fp16_kernel_is_fp32_accurate(shdr, shape, monkeypatch):
         assert rel_err(host(y0), oracle_conv(x, w2, x2=x2)) <= TOL
 
 
+def _local_rel(y, ref, x_like, w):
+    """worst error of an output pixel relative to the magnitude scale of ITS OWN receptive field (a 3 x 3 box maximum of |input|
+    times the filter norm) -- unlike rel_err, which divides by the tensor maximum and hides small-magnitude regions next to large ones"""
+    import scipy.ndimage as ndi
+    mag = np.abs(x_like).max(axis=-1)
+    box = ndi.maximum_filter(mag, size=(1, w.shape[0], w.shape[1]), mode="constant")
+    scale = box[..., None] * float(np.abs(w).sum(axis=(0, 1, 2)).max()) + 1e-300
+    return float((np.abs(np.asarray(y, np.float64) - ref) / scale).max())
+
+
+RANGE_CASES = [("x3_64_128", 2, 48, 64, 64, 0, 128, 3), ("x3_two_sources", 1, 64, 64, 32, 32, 64, 3), ("x3_1x1_256", 1, 64, 64, 256, 0, 64, 1),
+               ("x3n_7x7_16_16", 1, 64, 64, 16, 0, 16, 7), ("x3n_3x3_16+16_16", 1, 48, 80, 16, 16, 16, 3), ("x3n_5x5_32_32", 1, 64, 64, 32, 0, 32, 5)]
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=[c[0] for c in RANGE_CASES])
+@pytest.mark.parametrize("known_range", [False, True], ids=["measured", "slot_from_producer"])
+def test_split_operand_forward_is_range_safe(shdr, case, known_range, monkeypatch):
+    """The split-operand plans (x3 / x3n) against the exact-fp32 plan of the SAME layer outside the fp16 range
+    (hallucination_net.py:47-48 and vgg16.py:33-35 are fp32 convolutions without a range limit): activations at 1e5 and 1e-7 scale, one
+    7e4 outlier in an O(1) tensor, +-inf inputs.  The input is scaled by a power of two taken from its range slot -- measured below the
+    ABI when the caller has none, or written by the producer's epilogue.  Finite cases: <= 1e-5 of the tensor maximum against the
+    float64 oracle (the bar of the exact kernels) AND <= 1e-5 of each output's own receptive-field scale, so that the O(1) region next
+    to the outlier is checked too; non-finite cases: the output is non-finite exactly where the exact plan's is, equal elsewhere."""
+    name, n, h, w, c1, c2, cout, k = case
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    K = shdr._ops
+    rng = np.random.default_rng(len(name) * 131 + k)
+    wt = f32(rng.normal(size=(k, k, c1 + c2, cout)) / np.sqrt(k * k * (c1 + c2)))
+    b = f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2) == name.split("_")[0]
+
+    def run(x, x2, exact):
+        monkeypatch.setattr(K, "EXACT_FP32", exact)
+        xd, x2d = dev(x), (None if x2 is None else dev(x2))
+        if known_range and not exact:           # the slots a producing kernel would have written (K: "range slots")
+            K.absmax_slot(xd)
+            if x2d is not None:
+                K.absmax_slot(x2d)
+        y = K.conv2d(xd, dev(wt), dev(b * bias_mag), x2=x2d, act1=K.ACT_LRELU)
+        if not exact:                           # ... and the slot this launch wrote for its consumer holds max |y|
+            assert hasattr(y, "_shdr_range")
+            got, want = float(y._shdr_range), float(y[torch.isfinite(y)].abs().max())
+            assert got == want or not np.isfinite(got), (got, want)
+        monkeypatch.setattr(K, "EXACT_FP32", False)
+        return host(y)
+
+    for label, mag, outlier in (("1e5", 1e5, None), ("1e-7", 1e-7, None), ("outlier_7e4", 1.0, 7e4), ("tiny_3e-30", 3e-30, None),
+                                ("huge_1e30", 1e30, None)):
+        bias_mag = mag
+        x = f32(rng.normal(size=(n, h, w, c1)) * mag)
+        x2 = f32(rng.normal(size=(n, h, w, c2)) * mag) if c2 else None
+        if outlier:
+            x[0, h // 3, w // 3, 1] = outlier
+        ref = oracle_conv(x, wt, b * bias_mag, x2=x2, act1=2)
+        y, ye = run(x, x2, False), run(x, x2, True)
+        assert np.isfinite(y).all(), label
+        e_split, e_exact = rel_err(y, ref), rel_err(ye, ref)
+        assert e_split <= TOL and e_split <= 4 * e_exact + 2e-7, (label, e_split, e_exact)
+        xa = x if x2 is None else np.concatenate([x, x2], -1)
+        l_split, l_exact = _local_rel(y, ref, xa, wt), _local_rel(ye, ref, xa, wt)
+        assert l_split <= TOL and l_split <= 4 * l_exact + 2e-7, (label, l_split, l_exact)
+    # non-finite inputs: +inf and -inf pixels
+    bias_mag = 1.0
+    x = f32(rng.normal(size=(n, h, w, c1)))
+    x2 = f32(rng.normal(size=(n, h, w, c2))) if c2 else None
+    x[0, 5, 7, 0] = np.inf
+    x[n - 1, h - 9, w - 4, c1 - 1] = -np.inf
+    y, ye = run(x, x2, False), run(x, x2, True)
+    bad, bad_e = ~np.isfinite(y), ~np.isfinite(ye)
+    assert bad_e.any() and np.array_equal(bad, bad_e)
+    assert np.abs(y[~bad] - ye[~bad]).max() <= TOL * np.abs(ye[~bad]).max()
+
+
+def test_split_operand_range_slots_travel_with_the_tensors(shdr, monkeypatch):
+    """conv -> pool -> conv chains hand the range slot on (no measuring pass), bound-preserving ops keep it, host-known bounds become
+    constant slots; a chain run with slots equals the chain run with every range measured, bit for bit (same power-of-two scale)"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    K = shdr._ops
+    rng = np.random.default_rng(5)
+    x = dev(f32(rng.normal(size=(2, 64, 64, 32)) * 3e5))
+    w1 = dev(f32(rng.normal(size=(3, 3, 32, 64)) / 17)).requires_grad_(True)
+    w2 = dev(f32(rng.normal(size=(3, 3, 64, 64)) / 24)).requires_grad_(True)
+    with torch.no_grad(), K.range_scope():
+        y1, p1 = K.conv2d_avgpool2(x, w1, None, act1=K.ACT_RELU)
+        assert y1._shdr_range is p1._shdr_range and float(y1._shdr_range) == float(y1.abs().max())
+        up = K.resize2x(K.maxpool2(p1))
+        assert up._shdr_range is p1._shdr_range
+        y2 = K.conv2d(up, w2)
+        c = K.clip(y2, 0.0, 1.0)
+        assert c._shdr_bound == 1.0 and float(K._range_of(c)) == 1.0
+        plain = K.conv2d(up.clone(), w2)              # no slot on the clone: measured below the ABI (possibly another power of two)
+        assert bool(torch.isfinite(y2).all()) and float((plain - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
+
+
 def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     """the input gradient of a wide 3x3 layer takes the split kernel too (shdr_conv2d_dgrad_f32), and conv + MaxPool2D pairs run as
     x3 + pooling; both vs the float64 reference"""
