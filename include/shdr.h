@@ -129,6 +129,12 @@ int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d,
                         const float* bias, const float* scale, const float* shift,
                         const float* residual, float* y, void* stream);
 
+/* the same; y_range (or NULL) = range slot that receives max |y| from the kernel's epilogue (see shdr_conv2d_fwd_prepared_ranged_f32) */
+int shdr_conv2d_fwd_yrange_f32(const shdr_conv2d_desc* d,
+                               const float* x1, const float* x2, const float* w,
+                               const float* bias, const float* scale, const float* shift,
+                               const float* residual, float* y, float* y_range, void* stream);
+
 /* ---- dispatch below the ABI: plan / prepare / run.  algo = SHDR_ALGO_AUTO resolves to one of these kernel families from the
  *      descriptor alone (and from whether a residual is fused), the same way in all the calls below. */
 enum {

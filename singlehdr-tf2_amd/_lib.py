@@ -69,6 +69,7 @@ SIGNATURES = {
     "shdr_crc32c": (ctypes.c_uint32, [c_ptr, ctypes.c_uint64, ctypes.c_uint32]),
     "shdr_same_pad": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "shdr_conv2d_fwd_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
+    "shdr_conv2d_fwd_yrange_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 10),
     "shdr_conv2d_plan_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_prepared_filter_elems_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_filter_is_plain_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),

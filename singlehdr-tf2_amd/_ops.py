@@ -323,7 +323,6 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     split = plan in (4, 5)             # SHDR_PLAN_X3 / X3N: the input is scaled by its range, the epilogue tracks the output's
     xr1 = _range_of(x_in) if split else None
     xr2 = _range_of(x2_in) if (split and x2 is not None) else None
-    yr = _new_slot(x.device) if split else None
     ws = None
     nws = int(lib.shdr_conv2d_workspace_bytes_f32(ctypes.byref(d), has_res))
     if nws > 256 or (nws > 0 and (not split or xr1 is None or (x2 is not None and xr2 is None))):
@@ -335,6 +334,8 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
         yp = torch.empty((n, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
         if out is None and plan not in (2, 4):      # the fused Winograd and split kernels can skip y
             out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    # the output's range slot: written by the epilogue of the split-operand and of the exact-fp32 MFMA / direct kernels (no extra pass)
+    yr = _new_slot(x.device) if (split or (plan in (0, 1) and prologue == PROLOGUE_NONE and out is not None)) else None
     rc = lib.shdr_conv2d_fwd_prepared_ranged_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
                                                  _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _ptr(xr1), _ptr(xr2),
                                                  _ptr(yr), _stream())

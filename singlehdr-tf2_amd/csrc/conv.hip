@@ -53,7 +53,18 @@ struct ConvArgs {
                               // input gradient / of an up-sampling conv are written in place, interleaved)
   int prec;        // 0: exact fp32 MFMA; 1: fp16 / 2: bf16 MFMA operands (fp32 in HBM and LDS, fp32 accumulate)
   int legacy_epilogue;   // SHDR_CONV_LEGACY_EPILOGUE: store straight from the accumulator layout (comparison)
+  unsigned* yr;          // range slot of the output (conv_x3.hip "Range"): atomicMax of max |y| over the stored values, or null
 };
+
+// max |y| of a wave -> the range slot: one atomicMax per wave, only if it exceeds what the slot holds (agent-scope load)
+__device__ __forceinline__ void conv_range_out(unsigned* slot, float m) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
+}
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -79,6 +90,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int img, int oh0,
                                               int ow0, int n0, int wm, int wn, int fi, int fg) {
+  float ym = 0.0f;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int r = wm * MT * 16 + mi * 16 + fi;
@@ -114,6 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
         }
         *reinterpret_cast<float4*>(a.y + (size_t)pix * a.y_cs + co) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       } else {  // ragged tail of a zero-padded filter (e.g. Cout = 3): scalar, unaligned-safe
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -125,10 +138,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           if (a.res) t += a.res[(size_t)pix * a.res_cs + co + e];
           t = shdr::act_apply(t, a.act2);
           a.y[(size_t)pix * a.y_cs + co + e] = t;
+          if (a.yr) ym = fmaxf(ym, fabsf(t));
         }
       }
     }
   }
+  if (a.yr) conv_range_out(a.yr, ym);
 }
 
 // Row-contiguous epilogue for the LDS-DMA kernel (BN >= 32, every output channel stored): in the MFMA accumulator layout a
@@ -159,6 +174,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
   const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 s4 = a.scale ? *reinterpret_cast<const float4*>(a.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 t4 = a.scale ? *reinterpret_cast<const float4*>(a.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float ym = 0.0f;
 #pragma unroll 4
   for (int e = tid; e < TOTAL; e += 256) {
     const int r = e / QR;
@@ -183,7 +199,9 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
       v.z = shdr::act_apply(v.z, a.act2); v.w = shdr::act_apply(v.w, a.act2);
     }
     *reinterpret_cast<float4*>(a.y + pix * a.y_cs + co) = v;
+    if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (a.yr) conv_range_out(a.yr, ym);
 }
 
 // FAST: (C1+C2) % 32 == 0 and the two sources split on a 32-channel boundary, so the tap,
@@ -1035,10 +1053,11 @@ extern "C" int shdr_same_pad(int in_size, int k, int stride, int* out_size, int*
   return SHDR_OK;
 }
 
-extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2,
+// y_range (or NULL): range slot that receives max |y| (atomicMax; see shdr_conv2d_fwd_prepared_ranged_f32) from the kernels' epilogues
+extern "C" int shdr_conv2d_fwd_yrange_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2,
                                    const float* w, const float* bias, const float* scale,
                                    const float* shift, const float* residual, float* y,
-                                   void* stream) {
+                                   float* y_range, void* stream) {
   SHDR_REQUIRE(d && x1 && w && y, SHDR_E_NULL, "conv2d: null desc/x1/w/y");
   SHDR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0 &&
                    d->KH > 0 && d->KW > 0 && d->stride > 0 && d->Ho > 0 && d->Wo > 0,
@@ -1066,6 +1085,7 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   ConvArgs a{};
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift;
   a.res = residual; a.y = y;
+  a.yr = reinterpret_cast<unsigned*>(y_range);
   a.N = d->N; a.H = d->H; a.W = d->W; a.C1 = d->C1; a.C2 = d->C2; a.Ct = d->C1 + d->C2;
   a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -1126,9 +1146,18 @@ extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, c
   if (algo == SHDR_ALGO_DIRECT) {
     SHDR_REQUIRE(cout_valid == a.Cout, SHDR_E_SHAPE, "conv2d: direct path does not take padded filters");
     SHDR_REQUIRE(a.w_bstride == 0, SHDR_E_SHAPE, "conv2d: direct path does not take per-image filters");
-    if (a.Cout <= 3) return launch_direct<3>(a, st);
-    if (a.Cout % 16 == 0) return launch_direct<16>(a, st);
-    return launch_direct<8>(a, st);
+    int rc;
+    if (a.Cout <= 3) rc = launch_direct<3>(a, st);
+    else if (a.Cout % 16 == 0) rc = launch_direct<16>(a, st);
+    else rc = launch_direct<8>(a, st);
+    if (rc || !y_range) return rc;
+    SHDR_REQUIRE(d->y_pix_stride <= 1 && y_cs == cout_valid, SHDR_E_SHAPE, "conv2d: y_range needs a dense output");
+    return shdr_absmax_f32(y, (int64_t)d->N * d->Ho * d->Wo * cout_valid, y_range, stream);     // the VALU kernel's epilogue does not track it
   }
   return shdr::fail(SHDR_E_SHAPE, "conv2d: unknown algo %d", d->algo);
+}
+
+extern "C" int shdr_conv2d_fwd_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* w, const float* bias,
+                                   const float* scale, const float* shift, const float* residual, float* y, void* stream) {
+  return shdr_conv2d_fwd_yrange_f32(d, x1, x2, w, bias, scale, shift, residual, y, nullptr, stream);
 }

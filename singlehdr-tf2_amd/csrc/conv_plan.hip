@@ -229,7 +229,8 @@ extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, co
       x2_range = slots + 1;
     }
   }
-  if (y_range && !split_plan(plan)) {
+  const bool epilogue_range = split_plan(plan) || ((plan == SHDR_PLAN_MFMA || plan == SHDR_PLAN_DIRECT) && d->prologue == SHDR_PROLOGUE_NONE && y);
+  if (y_range && !epilogue_range) {
     // plans whose epilogue does not track the output range: one pass over the output(s) after the convolution
     SHDR_REQUIRE(d->y_pix_stride <= 1 && (d->y_cstride == 0 || d->y_cstride == (d->cout_valid > 0 ? d->cout_valid : d->Cout)), SHDR_E_SHAPE,
                  "conv2d_fwd_prepared: y_range needs a dense output");
@@ -299,7 +300,7 @@ extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, co
     shdr_conv2d_desc g = *d;
     g.x2_scale = 1.0f;                                   // folded into the prepared filter
     if (g.algo == SHDR_ALGO_AUTO_EXACT) g.algo = SHDR_ALGO_AUTO;
-    rc = shdr_conv2d_fwd_f32(&g, x1, x2, prepared, bias, scale, shift, residual, y, stream);
+    rc = shdr_conv2d_fwd_yrange_f32(&g, x1, x2, prepared, bias, scale, shift, residual, y, y_range, stream);
   }
   if (rc) return rc;
   if (y_pool) {

@@ -33,8 +33,6 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "shdr_internal.h"
 
 namespace {
@@ -81,8 +79,6 @@ struct X3Args {
   const unsigned* xr1;     // range slots of the two sources (bits of an upper bound of max |x|; null: no scaling)
   const unsigned* xr2;
   unsigned* yr;            // range slot of the output: atomicMax of max |y| (null: not wanted)
-  int dbg;                 // timing ablations of the paired-wave kernel (SHDR_X3P_DBG; results are wrong with any bit set)
-  unsigned long long* stamps;   // dbg & 64: s_memtime stamps of block 0 (diagnostic build only)
 };
 
 // 2^T and 2^-T for the power of two that brings the larger of the two bounds into [2^10, 2^11); 1 for an empty, zero or non-finite bound
@@ -459,352 +455,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #undef filt
 #undef lrs
 
-// ======================================================================================================================================
-// The paired-wave form of the same kernel ("x3p"): 512 threads, ONE persistent block per CU, explicit ping-pong of the two waves of a SIMD.
-//
-// Why.  PMC on the kernel above (profiles/r03_x3_pmc_before.txt): the matrix pipes are busy 0.62 of the cycles on the deepest layers
-// (16 chunks per block) and vector and matrix instructions co-execute in only 8 % of the matrix-busy cycles; 2 x 4 waves of two
-// independent blocks run the same program on each SIMD and fall into step -- both reach their barrier / operand-read / split phases
-// together and leave the pipe idle, then share it.  Cutting the split from 19 to 12 vector instructions per float4 changed nothing:
-// the pipe waits for the phases, not for the instruction count.  On the 512^2 layers with 2-4 chunks per tile a block additionally pays
-// its prologue (first patch: an HBM round trip) and epilogue once per 18-36 taps.
-// Here the two waves of a SIMD are the two cout halves of ONE block (group g = wave >> 2) and alternate by construction: in every
-// half-step (between two workgroup barriers) one group issues the 48 (24) MFMAs of a tap from operands already in registers while the
-// other reads its next tap's operands from LDS (asm, outside the compiler's view of LDS), forms wh 2^-11, issues the filter DMA two
-// taps ahead and does its share of the staging of the NEXT chunk's patch (one float4 per thread and half-step).  The block is
-// persistent: "next chunk" runs over tile boundaries, so the next tile's first patch and filter units are in flight under the current
-// tile's last taps and the epilogue of a group overlaps the other group's MFMAs.
-//   * block tile 16 x 16 pixels x 32 PNT couts (PNT = 4: 128, PNT = 2: 64); wave = 4 pixel rows x 16 PNT couts
-//   * patch: two fp16 images per chunk as above (same swizzle, same operand addressing), DOUBLE-buffered (chunk parity); both groups
-//     read the same buffer, all 512 threads stage the next one
-//   * filter: per group a ring of three units (one tap: wh + wl images of the group's couts) filled by LDS-DMA from a packed filter
-//     whose 16-byte slots are pre-swizzled in global memory, so the DMA is a linear copy: no registers, no ds_write
-//   * counted waits (static per tap position): every wave issues the same vector-memory operations in every half-step (dummy ones
-//     read valid addresses), "s_waitcnt vmcnt(N)" at the end of a compute phase = the filter unit of the NEXT tap has landed; the
-//     patch loads issued at tap 0 stay in flight for three full taps
-template <int KH, int KW, int PNT>
-struct XPG {
-  static constexpr int PH = 16 + KH - 1, PWID = 16 + KW - 1, PPIX = PH * PWID, NTAPS = KH * KW;
-  static constexpr int PJ = (PPIX * 8 + 511) / 512;             // float4 pieces per thread and chunk
-  static constexpr int PATCH_BYTES = PPIX * 64;                 // one fp16 image of a chunk's patch
-  static constexpr int PBUF_BYTES = 2 * PATCH_BYTES;            // high + low
-  static constexpr int GROWS = 16 * PNT;                        // couts of a group
-  static constexpr int GIMG_BYTES = GROWS * 64;                 // one image of a group's filter unit
-  static constexpr int GU_BYTES = 2 * GIMG_BYTES;               // wh + wl
-  static constexpr int GU_HALVES = GU_BYTES / 2;
-  static constexpr int RING = 3;
-  static constexpr int DW = GU_BYTES / 4096;                    // 1 KiB DMA instructions per wave and unit (PNT / 2)
-  static constexpr int FILT0 = 2 * PBUF_BYTES;                  // byte offset of the two filter rings
-  static constexpr int LDS_BYTES = FILT0 + 2 * RING * GU_BYTES;
-  static constexpr int TS = NTAPS - PJ;                         // first tap whose load phase stages a piece of the next chunk
-  static_assert(TS >= 3 && DW >= 1 && LDS_BYTES <= 160 * 1024, "tap count / tile not supported by the paired-wave kernel");
-};
-
-typedef __attribute__((address_space(1))) const void* xp_gptr_t;
-typedef __attribute__((address_space(3))) void* xp_lptr_t;
-constexpr int xp_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }     // s_waitcnt vmcnt(n) alone (gfx9 encoding)
-constexpr int xp_lgkmcnt(int n) { return 0xC07F | (n << 8); }
-
-template <int OFF>
-__device__ __forceinline__ f16x8 xp_lds_read(unsigned addr) {                       // outside the compiler's view of LDS (see above)
-  f16x8 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-template <int T0, int N, typename F>
-__device__ __forceinline__ void xp_static_for(F&& f) {
-  if constexpr (T0 < N) {
-    f(std::integral_constant<int, T0>{});
-    xp_static_for<T0 + 1, N>(f);
-  }
-}
-
-template <int KH, int KW, int PNT>
-__global__ __launch_bounds__(512) void conv_x3p_kernel(const X3Args a) {
-  using G = XPG<KH, KW, PNT>;
-  constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, NTAPS = G::NTAPS, DW = G::DW, TS = G::TS;
-  extern __shared__ __attribute__((aligned(16))) _Float16 psm[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave >> 2, wr = wave & 3;                       // group = cout half of the block, wr = pixel rows 4 wr .. 4 wr + 3
-  const int fi = lane & 15, fg = lane >> 4, pc = pcol(fi);
-  const unsigned lds0 = (unsigned)(unsigned long)(xp_lptr_t)psm;
-  const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5, nunits = nch * NTAPS;
-  const int ntiles = a.nblk_m * a.nblk_n;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-
-  struct Tile { int pn, img, oh0, ow0; };
-  auto decode = [&](int ti) __attribute__((always_inline)) {    // ti-th tile of this block
-    const int t = (int)blockIdx.x + ti * (int)gridDim.x;
-    const int L = xcd_remap(t < ntiles ? t : (int)blockIdx.x, ntiles);
-    Tile r;
-    r.pn = L % a.nblk_n;
-    int pm = L / a.nblk_n;
-    const int tx = pm % a.tiles_x;
-    pm /= a.tiles_x;
-    r.oh0 = (pm % a.tiles_y) * 16;
-    r.ow0 = tx * 16;
-    r.img = pm / a.tiles_y;
-    return r;
-  };
-
-  // ---- patch staging: piece p = tid + 512 j -> (patch pixel, float4 of the 32-channel chunk) ------------------------------------------
-  int ppix[PJ];                                                 // pixel index in the input tensor of the tile being prefetched; -1: zero
-  int pdst[PJ];                                                 // byte offset of the 8-byte destination inside an image; -1: no piece
-#pragma unroll
-  for (int j = 0; j < PJ; ++j) {
-    const int p = tid + 512 * j, pix = p >> 3, q = p & 7;
-    const int px = pix % PWID;
-    pdst[j] = pix < PPIX ? 2 * (pix * 32 + 8 * ((q >> 1) ^ sx(px)) + 4 * (q & 1)) : -1;
-  }
-  auto geometry = [&](const Tile& t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-      const int p = tid + 512 * j, pix = p >> 3;
-      const int py = pix / PWID, px = pix - py * PWID;
-      const int ih = a.in_s * (t.oh0 + py) + a.bh, iw = a.in_s * (t.ow0 + px) + a.bw;
-      const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-      ppix[j] = ok ? (t.img * a.Hin + ih) * a.Win + iw : -1;
-    }
-  };
-  f32x4 pr[PJ];
-  auto load_patch = [&](int c) __attribute__((always_inline)) {                                // chunk c of the geometry's tile -> registers
-    const bool second = c >= nch1;
-    const float* src = second ? a.x2 : a.x1;
-    const int Cs = second ? a.C2 : a.C1;
-    const int c0 = ((second ? c - nch1 : c) << 5) + 4 * (tid & 7);
-#pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-      // every thread issues every load (the waits are counted): padding / idle pieces read pixel 0 and are zeroed afterwards
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)(ppix[j] >= 0 ? ppix[j] : 0) * (unsigned)Cs + c0);
-      pr[j] = v;
-    }
-  };
-  float xs, ixs;
-  x3_range_scale(a.xr1, a.xr2, xs, ixs);
-  auto stage_piece = [&](int j, unsigned pbuf) __attribute__((always_inline)) {                 // registers -> the two fp16 images of buffer pbuf
-    if (pdst[j] < 0) return;
-    f32x4 v = pr[j];
-    if (ppix[j] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned h[2], l[2];
-    x3_split4(v, xs, h, l);
-    char* d = reinterpret_cast<char*>(psm) + pbuf + pdst[j];
-    *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
-    *reinterpret_cast<uint2*>(d + G::PATCH_BYTES) = make_uint2(l[0], l[1]);
-  };
-
-  // ---- filter DMA: unit u of tile t -> ring slot; wave wr of group g copies DW KiB of the group's 4 DW KiB unit --------------------------
-  const _Float16* wgrp = a.wp + (size_t)g * nunits * G::GU_HALVES;             // + pn * 2 groups
-  auto issue_dma = [&](int pn, int u, int slot) __attribute__((always_inline)) {
-    const _Float16* src = wgrp + ((size_t)pn * 2 * nunits + u) * G::GU_HALVES + (wr * DW) * 512 + lane * 8;
-    char* dst = reinterpret_cast<char*>(psm) + G::FILT0 + (g * G::RING + slot) * G::GU_BYTES + (wr * DW) * 1024;
-#pragma unroll
-    for (int i = 0; i < DW; ++i) __builtin_amdgcn_global_load_lds((xp_gptr_t)(src + i * 512), (xp_lptr_t)(dst + i * 1024), 16, 0, 0);
-  };
-
-  // ---- operand addresses (bytes) -------------------------------------------------------------------------------------------------------
-  unsigned alane[KW];
-#pragma unroll
-  for (int kw = 0; kw < KW; ++kw) alane[kw] = lds0 + 2u * (unsigned)((wr * MT) * PWID * 32 + (pc + kw) * 32 + 8 * (fg ^ sx(pc + kw)));
-  const unsigned blane = lds0 + G::FILT0 + g * G::RING * G::GU_BYTES + 2u * (unsigned)(fi * 32 + 8 * (fg ^ f4(fi)));
-
-  f32x4 acc[MT][PNT];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < PNT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  zero_acc();
-  float ym = 0.0f;
-
-  // ---- epilogue of one tile (the group's 16 PNT couts): y = act2(affine(act1(acc 2^-S + bias))), optional 2 x 2 pooled output ------------
-  const float inv_s = a.hdr[1] * ixs;
-  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
-    const int n0 = t.pn * (2 * G::GROWS) + g * G::GROWS;
-    const int ow = t.ow0 + pc;
-    f32x4 bias_r[PNT], scale_r[PNT], shift_r[PNT];
-#pragma unroll
-    for (int ni = 0; ni < PNT; ++ni) {
-      const int cl = n0 + ni * 16 + 4 * fg;
-      bias_r[ni] = (a.bias && a.final) ? *reinterpret_cast<const f32x4*>(a.bias + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      scale_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.scale + cl) : (f32x4){1.f, 1.f, 1.f, 1.f};
-      shift_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.shift + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp) {
-      const int oh = t.oh0 + wr * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
-      if (oh >= a.H) continue;                                   // wave-uniform
-#pragma unroll
-      for (int ni = 0; ni < PNT; ++ni) {
-        const int cl = n0 + ni * 16 + 4 * fg;
-        f32x4 v[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          v[r] = acc[2 * mp + r][ni] * inv_s;
-          const bool inside = oh + r < a.H && ow < a.W;
-          const size_t o = ((size_t)(t.img * a.H + oh + r) * a.W + ow) * a.Cout + cl;
-          if (a.yin && inside) v[r] += *reinterpret_cast<const f32x4*>(a.yin + o);
-          if (!a.final) {
-            if (inside) *reinterpret_cast<f32x4*>(a.y + o) = v[r];
-            continue;
-          }
-          v[r] += bias_r[ni];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act1);
-          if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
-          if (a.y && inside) *reinterpret_cast<f32x4*>(a.y + o) = v[r];
-          if (a.yr && inside) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[r][0]), fabsf(v[r][1]))), fmaxf(fabsf(v[r][2]), fabsf(v[r][3])));
-        }
-        if (a.yp && a.final) {
-          f32x4 m;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (a.pool_avg) {
-              const float tt = v[0][e] + __shfl_xor(v[0][e], 1, 64), bb = v[1][e] + __shfl_xor(v[1][e], 1, 64);
-              m[e] = 0.25f * (tt + bb);
-            } else {
-              m[e] = fmaxf(v[0][e], v[1][e]);
-              m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
-            }
-          }
-          if (!(pc & 1) && ow < a.W)
-            *reinterpret_cast<f32x4*>(a.yp + ((size_t)(t.img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + cl) = m;
-        }
-      }
-    }
-  };
-
-  // ---- prologue: first patch, first two filter units ------------------------------------------------------------------------------------
-  Tile cur = decode(0), nxt = cur, prev = cur;
-  geometry(cur);
-  load_patch(0);
-  issue_dma(cur.pn, 0, 0);
-  {
-    const bool in_tile = nunits > 1;                             // (always: NTAPS >= 9)
-    issue_dma(in_tile ? cur.pn : cur.pn, in_tile ? 1 : 0, 1);
-  }
-#pragma unroll
-  for (int j = 0; j < PJ; ++j) stage_piece(j, 0u);
-  __builtin_amdgcn_s_waitcnt(xp_vmcnt(0) & xp_lgkmcnt(0));
-  __builtin_amdgcn_s_barrier();
-  if (g == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one half-step behind group 0
-
-  int slot = 0;                                                  // ring slot of the current unit
-  unsigned pb_cur = 0u;                                          // byte offset of the patch buffer of the current chunk (0 / PBUF_BYTES)
-  bool have_next = false;                                        // the prefetch registers hold a real chunk
-  int n_ti = 0, n_c = 0;                                         // (tile, chunk) the prefetch registers belong to
-
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    for (int c = 0; c < nch; ++c) {
-      xp_static_for<0, NTAPS>([&](auto tapc) __attribute__((always_inline)) {
-        constexpr int tap = decltype(tapc)::value;
-        constexpr int kh = tap / KW, kw = tap % KW;
-        const int u = c * NTAPS + tap;
-        // =========================== load phase ===========================
-        // The loading wave outranks its SIMD partner's MFMA stream at the issue port (s_setprio): it has ~60 short instructions and then
-        // waits on LDS latency; unprioritised, the younger wave of the pair is starved by the partner's always-ready MFMAs and the two
-        // phases run one after the other instead of side by side (ablation: 768 + 630 cycles per half-step instead of max of the two)
-#define XP_STAMP(k) do { if (stamp_on && lane == 0) a.stamps[((stamp_i * 6) + (k)) * 8 + wave] = __builtin_amdgcn_s_memtime(); } while (0)
-        const bool stamp_on = (a.dbg & 64) && blockIdx.x == 0 && ti == 0 && c >= 4 && c < 6;
-        const int stamp_i = (c - 4) * NTAPS + tap;
-        XP_STAMP(0);
-        if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
-        // the tap's operands first: their LDS latency runs under the staging work below
-        f16x8 wh[PNT], wl[PNT], ph[MT], pl[MT];
-        if (!(a.dbg & 2)) {
-          const unsigned bb = blane + (unsigned)slot * G::GU_BYTES;
-          const unsigned aa = alane[kw] + pb_cur;
-          xp_static_for<0, PNT>([&](auto nic) __attribute__((always_inline)) {
-            constexpr int ni = decltype(nic)::value;
-            wh[ni] = xp_lds_read<ni * 1024>(bb);
-            wl[ni] = xp_lds_read<ni * 1024 + G::GIMG_BYTES>(bb);
-          });
-          xp_static_for<0, MT>([&](auto mic) __attribute__((always_inline)) {
-            constexpr int mi = decltype(mic)::value;
-            ph[mi] = xp_lds_read<(kh + mi) * PWID * 64>(aa);
-            pl[mi] = xp_lds_read<(kh + mi) * PWID * 64 + G::PATCH_BYTES>(aa);
-          });
-        }
-        if (tap == 0 && c == 0 && ti > 0) {                      // the previous tile's result: stored while the other group computes
-          epilogue(prev);
-          zero_acc();
-        }
-        if constexpr (tap >= TS) {                               // one piece of the next chunk per half-step
-          if (have_next && !(a.dbg & 8)) stage_piece(tap - TS, pb_cur ^ (unsigned)G::PBUF_BYTES);
-        }
-        if (!(a.dbg & 4)) {                                      // filter unit two taps ahead (always issued: the waits are counted)
-          int u2 = u + 2, pn2 = cur.pn;
-          if (u2 >= nunits) {
-            u2 -= nunits;
-            pn2 = nxt.pn;
-            if (ti + 1 >= my_tiles) { u2 = 0; pn2 = cur.pn; }    // beyond the last unit: a dummy copy into a slot nobody reads again
-          }
-          issue_dma(pn2, u2, slot >= 1 ? slot - 1 : 2);          // (slot + 2) % 3
-        }
-        if constexpr (tap == 0) {                                // the next chunk's patch: in flight for three taps
-          n_ti = ti;
-          n_c = c + 1;
-          if (n_c == nch) {
-            n_c = 0;
-            n_ti = ti + 1;
-            nxt = decode(n_ti);
-            if (n_ti < my_tiles) geometry(nxt);
-          }
-          have_next = n_ti < my_tiles;
-          if (!(a.dbg & 16)) load_patch(have_next ? n_c : 0);
-        }
-        __builtin_amdgcn_s_waitcnt(xp_lgkmcnt(0));
-        __builtin_amdgcn_sched_barrier(0);
-        XP_STAMP(1);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        XP_STAMP(2);
-        // =========================== compute phase ===========================
-#pragma unroll
-        for (int ni = 0; ni < PNT; ++ni) asm volatile("" : "+v"(wh[ni]), "+v"(wl[ni]));
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(ph[mi]), "+v"(pl[mi]));
-        if (!(a.dbg & 1))
-#pragma unroll
-        for (int ni = 0; ni < PNT; ++ni) {                       // cout tile outer: wh 2^-11 lives in four registers at a time
-          const f16x8 ws = wh[ni] * (_Float16)(1.0f / 2048.0f);  // exact (power of two)
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ph[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws, pl[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ph[mi], acc[mi][ni], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < PNT; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
-        // the NEXT tap's filter unit has landed (this wave's pieces; the barrier makes it everybody's): everything but the DW copies
-        // issued in this tap's load phase -- and, for two taps, the PJ patch loads -- is complete
-        XP_STAMP(3);
-        __builtin_amdgcn_s_waitcnt(xp_vmcnt(tap <= 1 ? DW + PJ : DW));
-        __builtin_amdgcn_sched_barrier(0);
-        XP_STAMP(4);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        XP_STAMP(5);
-        slot = slot == 2 ? 0 : slot + 1;
-      });
-      pb_cur ^= (unsigned)G::PBUF_BYTES;
-    }
-    prev = cur;
-    cur = nxt;
-  }
-  epilogue(prev);
-  if (g == 0) __builtin_amdgcn_s_barrier();                      // (every wave executes the same number of barriers)
-  __builtin_amdgcn_s_waitcnt(xp_vmcnt(0));                       // no LDS-DMA of this block is in flight when its LDS is released
-  if (a.yr && a.final) x3_range_out(a.yr, ym, lane);
-}
-
 // ---- filter preparation ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
   float m = 0.f;
@@ -858,40 +508,6 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
   }
 }
 
-// The paired-wave kernel's packed filter: [group of GROWS couts][unit][image: wh, wl][row][16-byte slot ^ f4(row)][8 halves] -- the LDS image of a
-// unit byte for byte (the swizzle is applied HERE), so that the kernel's LDS-DMA is a linear copy
-__global__ __launch_bounds__(256) void x3p_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int Ct,
-                                                       int C1, int Cout, float x2_scale, int KWF, int TH, int TW, int p0, int q0, int step, int GROWS) {
-  const float mx = fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[0]) * fmaxf(1.0f, fabsf(x2_scale)), 1e-30f);
-  int ex;
-  frexpf(mx, &ex);
-  int S = 14 - ex;
-  S = S < -100 ? -100 : (S > 100 ? 100 : S);
-  const float s = ldexpf(1.0f, S);
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
-  const int ntaps = TH * TW;
-  const int nunits = (Ct >> 5) * ntaps;
-  const long total = (long)Cout * nunits * 32;
-  const int img_halves = GROWS * 32;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int k = (int)(e & 7), slotp = (int)((e >> 3) & 3);
-    const long r = e >> 5;
-    const int row = (int)(r % GROWS);
-    const long t = r / GROWS;
-    const int u = (int)(t % nunits), grp = (int)(t / nunits);
-    const int chunk = u / ntaps, t2 = u - ntaps * chunk;
-    const int ta = t2 / TW, tb = t2 - TW * ta;
-    const int tap = (p0 + step * ta) * KWF + (q0 + step * tb);
-    const int ch = chunk * 32 + 8 * (slotp ^ f4(row)) + k;
-    float v = w[((size_t)tap * Ct + ch) * Cout + grp * GROWS + row] * s;
-    if (ch >= C1) v *= x2_scale;
-    const _Float16 h = (_Float16)v;
-    _Float16* o = out + ((size_t)grp * nunits + u) * 2 * img_halves + row * 32 + slotp * 8 + k;
-    o[0] = h;
-    o[img_halves] = (_Float16)(v - (float)h);
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -926,67 +542,6 @@ int launch_x3(const X3Args& a, hipStream_t st) {
   if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
   hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_x3_kernel");
-}
-
-template <int KH, int KW, int PNT>
-int launch_x3p(const X3Args& a, hipStream_t st) {
-  constexpr int lds = XPG<KH, KW, PNT>::LDS_BYTES;
-  static bool attr_done[shdr::kMaxDevices] = {};
-  static int cus[shdr::kMaxDevices] = {};
-  const int dev_slot = shdr::device_slot();
-  if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<KH, KW, PNT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    cus[dev_slot] = n;
-    attr_done[dev_slot] = true;
-  }
-  const long ntiles = (long)a.nblk_m * a.nblk_n;
-  if (ntiles > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: %ld tiles", ntiles);
-  const unsigned grid = (unsigned)(ntiles < cus[dev_slot] ? ntiles : cus[dev_slot]);      // persistent: one block per CU
-  if (a.dbg & 64) {                                               // diagnostic: stamps of block 0, printed to stderr
-    static unsigned long long* buf = nullptr;
-    constexpr int N = 2 * 16 * 6 * 8;
-    if (!buf && hipMalloc(&buf, N * 8) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "stamps");
-    (void)hipMemset(buf, 0, N * 8);
-    X3Args b = a;
-    b.stamps = buf;
-    hipLaunchKernelGGL((conv_x3p_kernel<KH, KW, PNT>), dim3(grid), dim3(512), lds, st, b);
-    (void)hipStreamSynchronize(st);
-    static unsigned long long h[N];
-    (void)hipMemcpy(h, buf, N * 8, hipMemcpyDeviceToHost);
-    const unsigned long long t0 = h[0];
-    for (int i = 0; i < 2 * KH * KW; ++i) {
-      fprintf(stderr, "unit %2d:", i);
-      for (int w = 0; w < 8; w += 4) {
-        fprintf(stderr, "  w%d", w);
-        for (int k = 0; k < 6; ++k) fprintf(stderr, " %6lld", (long long)(h[(i * 6 + k) * 8 + w] - t0));
-      }
-      fprintf(stderr, "\n");
-    }
-    return shdr::check_launch("conv_x3p_kernel");
-  }
-  hipLaunchKernelGGL((conv_x3p_kernel<KH, KW, PNT>), dim3(grid), dim3(512), lds, st, a);
-  return shdr::check_launch("conv_x3p_kernel");
-}
-
-// the bilinear 2x prologue runs inside the (4-wave) kernel's patch loader where the up-sampling pass is dear next to the convolution
-// (conv_plan.hip: up2_in_kernel)
-inline bool x3_up_in_kernel(const shdr_conv2d_desc* d) {
-  return d->prologue == SHDR_PROLOGUE_BILINEAR2X && d->C2 == 0 && d->KH == 3 && d->stride == 1 && (d->Cout <= 256 || SHDR_ENV("SHDR_X3_UP_ALWAYS") != nullptr);
-}
-// couts per wave tile (4: blocks of 128 couts, 2: blocks of 64) if the layer runs on the paired-wave kernel (and its filter is packed for
-// it), 0 if on the 4-wave kernel above.  A function of the descriptor alone, the same at prepare and at launch time.
-int x3p_pnt(const shdr_conv2d_desc* d) {
-  if (SHDR_ENV("SHDR_NO_X3P") || x3_up_in_kernel(d)) return 0;
-  if (!((d->stride == 1 && d->KH == 3 && d->KW == 3) || (d->stride == 2 && d->KH == 7 && d->KW == 7))) return 0;
-  int pnt = d->Cout % 128 == 0 ? 4 : 2;
-  if (const char* e = SHDR_ENV("SHDR_X3P_PNT")) pnt = (atoi(e) == 4 && d->Cout % 128 == 0) ? 4 : 2;      // experiments: force the 64-cout block
-  const long tiles = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / (32 * pnt));
-  long min_tiles = 200;                                          // one block per CU: at least most of a round
-  if (const char* e = SHDR_ENV("SHDR_X3P_MIN_TILES")) min_tiles = atol(e);
-  return tiles >= min_tiles ? pnt : 0;
 }
 
 }  // namespace
@@ -1038,7 +593,6 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
   const float x2s = d->C2 > 0 ? d->x2_scale : 1.0f;
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
-  const int pnt = x3p_pnt(d);                                    // which kernel's packed layout
   const long nw = (long)d->KH * d->KW * Ct * d->Cout;
   float* out = prepared;
   for (int i = 0; i < n; ++i) {
@@ -1047,12 +601,8 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
     const int gmax = shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64;
     hipLaunchKernelGGL(x3_absmax_kernel, dim3(gmax), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
     const long np = (long)ph[i].th * ph[i].tw * Ct * d->Cout;
-    if (pnt)
-      hipLaunchKernelGGL(x3p_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS),
-                         Ct, d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step, 16 * pnt);
-    else
-      hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
-                         d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);
+    hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
+                       d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);
     out += x3_phase_floats(ph[i], Ct, d->Cout);
   }
   return shdr::check_launch("conv2d_x3_prepare_filter");
@@ -1112,13 +662,11 @@ extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const fl
   a.xr1 = reinterpret_cast<const unsigned*>(x1_range);
   a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);
   a.yr = reinterpret_cast<unsigned*>(y_range);
-  if (const char* e = SHDR_ENV("SHDR_X3P_DBG")) a.dbg = atoi(e);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
   SHDR_REQUIRE(n == 1 || y, SHDR_E_NULL, "conv2d_x3: the phases of a stride-2 layer accumulate in y");
   const int Ct = d->C1 + d->C2;
-  const int pnt = x3p_pnt(d);
   const float* pk = prepared;
   for (int i = 0; i < n; ++i) {
     a.hdr = pk;
@@ -1128,14 +676,7 @@ extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const fl
     a.yin = i > 0 ? y : nullptr;
     a.final = i == n - 1;
     int rc;
-    if (pnt) {
-      a.nblk_n = a.Cout / (32 * pnt);
-      if (ph[i].th == 3 && ph[i].tw == 3) rc = pnt == 4 ? launch_x3p<3, 3, 4>(a, st) : launch_x3p<3, 3, 2>(a, st);
-      else if (ph[i].th == 4 && ph[i].tw == 4) rc = pnt == 4 ? launch_x3p<4, 4, 4>(a, st) : launch_x3p<4, 4, 2>(a, st);
-      else if (ph[i].th == 4 && ph[i].tw == 3) rc = pnt == 4 ? launch_x3p<4, 3, 4>(a, st) : launch_x3p<4, 3, 2>(a, st);
-      else if (ph[i].th == 3 && ph[i].tw == 4) rc = pnt == 4 ? launch_x3p<3, 4, 4>(a, st) : launch_x3p<3, 4, 2>(a, st);
-      else rc = shdr::fail(SHDR_E_SHAPE, "conv2d_x3: no paired-wave kernel for a %d x %d phase", ph[i].th, ph[i].tw);
-    } else if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
+    if (ph[i].th == 3 && ph[i].tw == 3) rc = up ? launch_x3<true, 3, 3>(a, st) : launch_x3<false, 3, 3>(a, st);
     else if (ph[i].th == 1 && ph[i].tw == 1) rc = launch_x3<false, 1, 1>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 4) rc = launch_x3<false, 4, 4>(a, st);
     else if (ph[i].th == 4 && ph[i].tw == 3) rc = launch_x3<false, 4, 3>(a, st);

@@ -198,10 +198,22 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
 #pragma unroll
     for (int j = 0; j < G::PJ; ++j) {
       if (pdst[j] < 0) continue;
-      unsigned h[2], l[2];
-      xn_split4(pr[j], xs, h, l);
-      *reinterpret_cast<uint2*>(patch_h + pdst[j]) = make_uint2(h[0], h[1]);
-      *reinterpret_cast<uint2*>(patch_l + pdst[j]) = make_uint2(l[0], l[1]);
+      if (ASM_LOADS) {
+        unsigned h[2], l[2];
+        xn_split4(pr[j], xs, h, l);
+        *reinterpret_cast<uint2*>(patch_h + pdst[j]) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(patch_l + pdst[j]) = make_uint2(l[0], l[1]);
+      } else {                                                 // the 7x7 image layers: compiler-scheduled split as well (0.16 vs 0.20 ms with the asm form)
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = pr[j][e] * xs;
+          h[e] = (_Float16)v;
+          l[e] = (_Float16)((v - (float)h[e]) * 2048.0f);
+        }
+        *reinterpret_cast<f16x4*>(patch_h + pdst[j]) = h;
+        *reinterpret_cast<f16x4*>(patch_l + pdst[j]) = l;
+      }
     }
   };
 

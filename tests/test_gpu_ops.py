@@ -493,6 +493,16 @@ def test_split_operand_range_slots_travel_with_the_tensors(shdr, monkeypatch):
         y2 = K.conv2d(up, w2)
         c = K.clip(y2, 0.0, 1.0)
         assert c._shdr_bound == 1.0 and float(K._range_of(c)) == 1.0
+        # the exact-fp32 MFMA / direct kernels track their output range too (their consumer may be a split-operand layer)
+        w3 = dev(f32(rng.normal(size=(1, 1, 64, 64)) / 8)).requires_grad_(True)
+        assert K.conv2d_plan(tuple(y2.shape), tuple(w3.shape)) == "mfma"
+        for kw in (dict(), dict(act1=K.ACT_RELU, residual=y2, act2=K.ACT_RELU)):
+            y3 = K.conv2d(y2, w3, **kw)
+            assert float(y3._shdr_range) == float(y3.abs().max())
+        w4 = dev(f32(rng.normal(size=(1, 1, 64, 3)))).requires_grad_(True)
+        assert K.conv2d_plan(tuple(y2.shape), tuple(w4.shape)) == "direct"
+        y4 = K.conv2d(y2, w4)
+        assert float(y4._shdr_range) == float(y4.abs().max())
         plain = K.conv2d(up.clone(), w2)              # no slot on the clone: measured below the ABI (possibly another power of two)
         assert bool(torch.isfinite(y2).all()) and float((plain - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
 
