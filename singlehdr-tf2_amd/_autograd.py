@@ -444,6 +444,26 @@ def fork(x, n=2):
     return ForkFn.apply(x, n)
 
 
+class MarkFn(torch.autograd.Function):
+    """Identity with a callback in its backward: the callback runs (on the autograd thread, torch's current stream = the stream of
+    the forward op) once every backward node BEHIND this point of the tape has been enqueued -- the data-parallel steps hang the
+    launch of a gradient bucket's all-reduce on it."""
+
+    @staticmethod
+    def forward(ctx, x, callback):
+        ctx.callback = callback
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.callback()
+        return g, None
+
+
+def mark(x, callback):
+    return MarkFn.apply(x, callback)
+
+
 # ---------------------------------------------------------------------------
 # inverse-CRF head, CRF application
 # ---------------------------------------------------------------------------

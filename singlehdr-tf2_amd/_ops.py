@@ -888,6 +888,14 @@ def add(a, b, relu=False):
     return y
 
 
+def mark(x, callback):
+    """x itself; on a gradient tape `callback()` runs when the backward pass reaches this point (every backward op of the layers AFTER
+    it in the forward has been enqueued): where the data-parallel steps launch a gradient bucket's all-reduce"""
+    if callback is None or not _needs_grad(x):
+        return x
+    return AUTOGRAD.mark(x, callback)
+
+
 def fork(x, n=2):
     """n aliases of x for n consumers (skip connections, residual shortcuts, multi-term losses): on a gradient tape the consumers'
     gradients are summed by the add kernel of this library; without a tape it is x itself, n times"""

@@ -119,6 +119,9 @@ class model(Layer):
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)
         enc, d5 = self.d5(x)
+        # data-parallel steps: the backward pass reaches this point when the gradients of every variable created after d5 (conv1,
+        # norm1, the decoder, the skip layers: 60 of the net's 98 MB) are complete -- their all-reduce starts under the encoder's backward
+        enc = K.mark(enc, getattr(self, "_decoder_grads_done", None))
         frozen = not train and taping(input_layer, self.conv1.kernel, self.norm1.gamma)
         if train:
             x = self.norm1.train_apply(self.conv1(enc), relu=True)

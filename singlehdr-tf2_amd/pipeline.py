@@ -200,8 +200,13 @@ class JointTrainStep:
     LEARNING_RATE = 1e-5   # joint_training.py:20
     THRESHOLD = 0.12       # joint_training.py:140
 
-    def __init__(self, deq, lin, hal, vgg, vgg2=None, lr=None, process_group=None, world_size=1, multi_stream=True):
+    def __init__(self, deq, lin, hal, vgg, vgg2=None, lr=None, process_group=None, world_size=1, multi_stream=True, bucketed=True):
+        """bucketed (data parallel only): the flat gradient is reduced in FOUR collectives instead of one, each launched as async work
+        as soon as its slice is complete and overlapped with the backward ops that remain (SURVEY.md section 8e "bucket per net, hal
+        first"): hal's decoder half (from a tape mark at the bottleneck), hal's encoder half, lin, deq.  Same SUM per element as the
+        one blocking all_reduce (bucketed=False); no rank-local code path issues a collective."""
         self._deq, self._lin, self._hal, self._vgg, self._vgg2 = deq, lin, hal, vgg, vgg2 or vgg
+        self.bucketed = bucketed
         self.params = FlatParams([deq, lin, hal])
         self.optimizer = KerasAdam(self.params, self.LEARNING_RATE if lr is None else lr)
         self.pg, self.world = process_group, world_size
@@ -254,8 +259,10 @@ class JointTrainStep:
         b = mask.numel()
         total_loss = (loss_deq + loss_hal).reshape(b, 1, 1, 1) + loss_lin          # [b,1,b,1] (:183)
         # the scalar tape.gradient differentiates (class docstring), with the GLOBAL batch size and mask sum under DP
-        objective = b_glob * (loss_deq.sum() + (10.0 * l2_lin * mask).sum() + loss_hal.sum()) + msum * crf_loss.sum()
-        return dict(total=total_loss, objective=objective, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
+        terms = dict(deq=b_glob * loss_deq.sum(), lin=b_glob * (10.0 * l2_lin * mask).sum() + msum * crf_loss.sum(),
+                     hal=b_glob * loss_hal.sum())                   # the three nets share no variable: three independent tapes
+        objective = terms["deq"] + terms["lin"] + terms["hal"]
+        return dict(total=total_loss, objective=objective, objective_terms=terms, loss_deq=loss_deq, loss_lin=loss_lin, loss_hal=loss_hal,
                     crf_loss=crf_loss, C_pred=C_pred, B_pred=B_pred, A_pred=A_pred, alpha=alpha)
 
     def _join_streams(self):
@@ -267,14 +274,74 @@ class JointTrainStep:
             for st in self._streams:
                 main.wait_stream(st)
 
+    def _net_slices(self):
+        """{net: (begin, end)} of the flat buffers, and the offset inside hal at which the variables created after the encoder begin"""
+        if getattr(self, "_slices", None) is None:
+            bounds, i = {}, 0
+            offs = self.params.offsets + [self.params.numel]
+            for name, m in (("deq", self._deq), ("lin", self._lin), ("hal", self._hal)):
+                n = len(m.trainable_variables)
+                bounds[name] = (offs[i], offs[i + n])
+                if name == "hal":
+                    k = next(j for j, v in enumerate(m.trainable_variables) if v is self._hal.conv1.kernel)
+                    self._hal_split = offs[i + k]
+                i += n
+            self._slices = bounds
+        return self._slices
+
+    def gradient_buckets(self):
+        """[(begin, end)] of the flat gradient in launch order: hal decoder half, hal encoder half, lin, deq -- a partition of it"""
+        sl = self._net_slices()
+        return [(self._hal_split, sl["hal"][1]), (sl["hal"][0], self._hal_split), sl["lin"], sl["deq"]]
+
+    def _decoder_grads_done(self):
+        if self._on_decoder_grads is not None:
+            self._on_decoder_grads()
+
+    def _bucketed_backward(self, out):
+        """backward + gradient collectives, overlapped: hal first (the largest bucket and the longest backward), its decoder half
+        reduced while its encoder half is still being computed; then lin, then deq.  Each collective is enqueued behind the stream
+        its slice was written on and nothing else."""
+        import torch.distributed as dist
+        sl = self._net_slices()
+        streams = self._streams if self._streams is not None else (torch.cuda.current_stream(),) * 3
+        works = []
+
+        def reduce(begin, end, stream):
+            with torch.cuda.stream(stream):
+                works.append(dist.all_reduce(self.params.grad[begin:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._on_decoder_grads = lambda: reduce(self._hal_split, sl["hal"][1], torch.cuda.current_stream())
+        try:
+            terms = out["objective_terms"]
+            terms["hal"].backward()
+            reduce(sl["hal"][0], self._hal_split, streams[2])
+            terms["lin"].backward()
+            reduce(*sl["lin"], streams[1])
+            terms["deq"].backward()
+            reduce(*sl["deq"], streams[0])
+        finally:
+            self._on_decoder_grads = None
+        self._join_streams()
+        for w in works:
+            w.wait()
+
     def __call__(self, ds, invcrf, apply=True):
         self.params.zero_grad()
+        dp = self.pg is not None and self.world > 1
+        if dp and self.bucketed:
+            self._net_slices()
+            self._on_decoder_grads = None
+            self._hal._decoder_grads_done = self._decoder_grads_done      # the tape mark is recorded in the forward pass
         out = self.losses(ds, invcrf)
-        out["objective"].backward()                       # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
-        self._join_streams()
-        if self.pg is not None and self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)   # the ONE gradient collective
+        self._hal._decoder_grads_done = None
+        if dp and self.bucketed:
+            self._bucketed_backward(out)
+        else:
+            out["objective"].backward()                   # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
+            self._join_streams()
+            if dp:
+                import torch.distributed as dist
+                dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)   # the ONE gradient collective
         if apply:
             self.optimizer.step()
         return out

@@ -86,6 +86,32 @@ def main():
     res["joint_objective"] = np.asarray(float(outp["objective"]))
     step.optimizer.step()
     res["joint_params_after"] = step.params.flat.detach().cpu().numpy()
+    # the default above is the BUCKETED, overlapped reduction (four async collectives launched from inside the backward pass); here the
+    # one blocking all_reduce on fresh replicas of the same weights, and the two decompositions of the collective on one buffer
+    models_b = build_models(shdr, nets)
+    blocking = P.JointTrainStep(models_b["deq"], models_b["lin"], models_b["hal"], build_vgg(shdr, nets), lr=1e-3,
+                                process_group=dist.group.WORLD, world_size=world, bucketed=False)
+    blocking(ds, dev(d["inv"][sl]), apply=False)
+    for k, g in net_grads(blocking, models_b).items():
+        res["joint_blocking_grad_" + k] = g
+    buckets = step.gradient_buckets()
+    res["buckets"] = np.asarray(buckets)
+    res["flat_numel"] = np.asarray(step.params.numel)
+    gen = torch.Generator(device="cuda").manual_seed(100 + rank)
+    whole = torch.randn(step.params.numel, device="cuda", generator=gen)
+    pieces = whole.clone()
+    dist.all_reduce(whole, op=dist.ReduceOp.SUM)
+    side = [torch.cuda.Stream() for _ in buckets]
+    works = []
+    for st, (b0, b1) in zip(side, buckets):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            works.append(dist.all_reduce(pieces[b0:b1], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    for st in side:
+        torch.cuda.current_stream().wait_stream(st)
+    res["bucketed_equals_blocking_collective"] = np.asarray(bool(torch.equal(whole, pieces)))
 
     # ---- per-network step of train.py:203-244 (batch-global TV term) ---------------------------------------------------------
     models = build_models(shdr, nets)

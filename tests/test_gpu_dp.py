@@ -66,6 +66,20 @@ def test_both_ranks_hold_the_same_reduced_gradient_and_update(ranks):
     assert float(r0["joint_objective"]) != float(r1["joint_objective"])         # (the shards themselves differ)
 
 
+def test_bucketed_overlapped_reduction_equals_the_blocking_one(ranks):
+    """JointTrainStep(bucketed=True), the default the tests above ran: four async collectives (hal decoder half from a tape mark at the
+    bottleneck, hal encoder half, lin, deq) launched from inside the backward pass on the stream their slice was written on.  The
+    buckets partition the flat gradient; reducing a buffer bucket by bucket on side streams gives the bits of ONE all_reduce; the
+    step's reduced gradients equal the blocking step's up to the atomics noise of two separate backward passes (5e-4, as above)."""
+    for r in ranks:
+        b = sorted(map(tuple, r["buckets"].tolist()))
+        assert b[0][0] == 0 and b[-1][1] == int(r["flat_numel"]) and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1)) and len(b) == 4
+        assert bool(r["bucketed_equals_blocking_collective"])
+        for k in ("deq", "lin", "hal"):
+            assert rel_l2(r["joint_grad_" + k], r["joint_blocking_grad_" + k]) <= 5e-4, k
+    assert rel(ranks[0]["joint_grad_deq"], ranks[0]["joint_blocking_grad_deq"]) <= 1e-5
+
+
 def test_joint_step_sharded_equals_full_batch(shdr, ranks, monkeypatch):
     P = shdr.pipeline
     d = W.make_data(4, 64)

@@ -119,6 +119,9 @@ def test_fp16_conv_forward_dgrad_wgrad_vs_float64_reference(shdr, case, kernels,
     assert rel_err(host(db.grad), tb.grad.numpy()) <= LAYER_TOL, "db"
 
 
+FT16_COS, FT16_NORM, FT16_INTER = 0.995, 0.02, 5e-3      # whole-step bars against the fp16-storage model
+
+
 @pytest.fixture(scope="module")
 def ft16(shdr, emor_table):
     rng = np.random.default_rng(12)
@@ -133,7 +136,13 @@ def ft16(shdr, emor_table):
     tP = {k: R.params_to_torch(v) for k, v in P.items()}
     ref = R.finetune_forward(tP, R.T(ldr), R.T(hdr), emor_table)
     ref["loss"].sum().backward()
-    return dict(step=step, ms=ms, ldr=dev(ldr), hdr=dev(hdr), ref=ref, tP=tP, P=P, np=(ldr, hdr))
+    # the float64 MODEL of the fp16 path (torch_ref.fp16_storage: float64 arithmetic, feature maps rounded to fp16 where the product
+    # stores fp16): its relu / max-pool / clip decisions are taken on the values the HIP forward sees
+    tQ = {k: R.params_to_torch(v) for k, v in P.items()}
+    with R.fp16_storage():
+        refq = R.finetune_forward(tQ, R.T(ldr), R.T(hdr), emor_table)
+        refq["loss"].sum().backward()
+    return dict(step=step, ms=ms, ldr=dev(ldr), hdr=dev(hdr), ref=ref, tP=tP, refq=refq, tQ=tQ, P=P, np=(ldr, hdr))
 
 
 def test_fp16_finetune_step_vs_float64_oracle(ft16, emor_table):
@@ -154,6 +163,32 @@ def test_fp16_finetune_step_vs_float64_oracle(ft16, emor_table):
     cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
     assert cos >= 0.95, cos
     assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1.0) <= 0.1
+    # ... and against the float64 model WITH fp16 storage (same activation masks up to accumulation rounding): the tight bars
+    refq = np.zeros_like(got)
+    for (net, n), o in zip(names, ft16["step"].params.offsets):
+        g = ft16["tQ"][net][n].grad.numpy().ravel()
+        refq[o:o + g.size] = g
+    cosq = float((got * refq).sum() / (np.linalg.norm(got) * np.linalg.norm(refq)))
+    normq = float(np.linalg.norm(got) / np.linalg.norm(refq))
+    errs = {k: rel_err(host(out[k]), ft16["refq"][k].detach().numpy()) for k in ("C_pred", "B_pred", "A_pred", "refinement_output")}
+    per_net, o0 = {}, 0
+    offs = list(ft16["step"].params.offsets) + [got.size]
+    for net in ("deq", "lin", "hal", "ref"):
+        nv = len(ft16["ms"][net].trainable_variables)
+        a, b = offs[o0], offs[o0 + nv]
+        per_net[net] = (float((got[a:b] * refq[a:b]).sum() / (np.linalg.norm(got[a:b]) * np.linalg.norm(refq[a:b]))),
+                        float(np.linalg.norm(got[a:b]) / np.linalg.norm(refq[a:b])), float(np.linalg.norm(refq[a:b])))
+        o0 += nv
+    print("fp16 step vs fp16-storage model: cos %.5f norm ratio %.4f intermediates %s (unrounded reference: cos %.5f)" % (cosq, normq, errs, cos))
+    print("  per net (cos, norm ratio, |g|):", {k: tuple(round(x, 5) for x in v) for k, v in per_net.items()})
+    # Measured (MI355X): deq 0.9993 / ref 1.0000 -- the two nets without BatchNorm meet the tight bars; lin 0.973 / hal 0.940 do not,
+    # and the fp16-storage model scores the SAME cosine as the unrounded reference (0.9736 vs 0.9745): the residual is not activation
+    # masks but training-mode BatchNorm on this fixture (2 x 64 x 64: 8 samples per channel at the Hallucination-Net bottleneck, where a
+    # 5e-4 fp16 perturbation of the input moves the batch statistics); the per-layer tests above hold every conv / BN kernel to 3e-3.
+    for net in ("deq", "ref"):
+        assert per_net[net][0] >= FT16_COS and abs(per_net[net][1] - 1.0) <= FT16_NORM + 0.01, (net, per_net[net])
+    assert per_net["lin"][0] >= 0.95 and per_net["hal"][0] >= 0.90 and cosq >= 0.95 and abs(normq - 1.0) <= FT16_NORM, (per_net, cosq, normq)
+    assert max(errs["C_pred"], errs["B_pred"]) <= FT16_INTER and max(errs.values()) <= 2e-2, errs
 
 
 def test_fp16_finetune_1024_tiles_properties(shdr):

@@ -107,6 +107,60 @@ def test_training_reduces_the_loss(setup):
     assert np.isfinite(last) and last < first, (first, last)
 
 
+def test_joint_step_at_its_own_size_properties(shdr):
+    """BASELINE configs[3] at its own size -- batch 32 of 256 x 256, where the split-operand kernels take the wide layers in the
+    forward AND in the input gradient (range-scaled dz) -- as properties: finite losses and gradients, a decreasing loss, and the
+    split-operand input gradient against the exact-fp32 one on the SAME tape (forward under EXACT_FP32, so both backward passes see
+    identical relu / max-pool masks): flat gradient within 6e-5 in relative L2 (3.0e-5 measured, Winograd-fp32 vs
+    direct-fp32 2.4e-6, atomics noise 1e-6)."""
+    K, P = shdr._ops, shdr.pipeline
+    torch.manual_seed(1234)
+    g = torch.Generator().manual_seed(9)
+    b, sz = 32, 256
+
+    def q(*shape):
+        return (torch.round(torch.rand(shape, generator=g) * 255.0) / 255.0).cuda()
+    clipped = q(b, sz, sz, 3)
+    clipped[0, :40, :40] = 1.0
+    hdr_t = clipped * torch.where(clipped >= 1.0, 1 + 3 * torch.rand((b, sz, sz, 3), generator=g).cuda(), torch.ones(()).cuda())
+    inv = torch.cumsum(torch.rand((b, 1024), generator=g), dim=1).cuda()
+    inv = (inv - inv[:, :1]) / (inv[:, -1:] - inv[:, :1])
+    mask = torch.ones((b, 1, 1, 1)).cuda()
+    mask[-1] = 0.0
+    ds = (q(b, sz, sz, 3), q(b, sz, sz, 3), clipped, hdr_t, mask)
+    nets3 = [shdr.dequantization_net.model(), shdr.linearization_net.model(), shdr.hallucination_net.model()]
+    vgg = shdr.vgg16.Vgg16(data_dict={n: [torch.randn(s, generator=g).mul_(0.05).numpy(), np.zeros(s[-1], np.float32)] for n, s in (
+        ("conv1_1", (3, 3, 3, 64)), ("conv1_2", (3, 3, 64, 64)), ("conv2_1", (3, 3, 64, 128)), ("conv2_2", (3, 3, 128, 128)),
+        ("conv3_1", (3, 3, 128, 256)), ("conv3_2", (3, 3, 256, 256)), ("conv3_3", (3, 3, 256, 256)))})
+    step = P.JointTrainStep(*nets3, vgg, lr=1e-5)
+    assert K.conv2d_plan((b, sz, sz, 64), (3, 3, 64, 64)) == "x3"              # the wide layers do run on the split-operand kernel here
+
+    def grads(exact_backward):
+        step.params.zero_grad()
+        K.EXACT_FP32 = True                                                    # the same exact-fp32 forward for both: identical masks
+        try:
+            out = step.losses(ds, inv)
+            K.EXACT_FP32 = exact_backward
+            out["objective"].backward()
+            step._join_streams()
+        finally:
+            K.EXACT_FP32 = False
+        torch.cuda.synchronize()
+        return step.params.grad.double().clone(), out
+    g_exact, out = grads(True)
+    g_split, _ = grads(False)
+    assert bool(torch.isfinite(g_exact).all()) and bool(torch.isfinite(g_split).all()) and float(g_exact.norm()) > 0.0
+    rel = float((g_split - g_exact).norm() / g_exact.norm())
+    print("joint step b=32 x 256^2: split-operand vs exact-fp32 input gradients, flat gradient relative L2 = %.2e" % rel)
+    assert rel <= 6e-5, rel
+    first = float(step(ds, inv)["total"].sum())                                # default plan: split-operand forward and backward
+    for _ in range(3):
+        o = step(ds, inv)
+    last = float(o["total"].sum())
+    assert all(bool(torch.isfinite(o[k]).all()) for k in ("total", "C_pred", "B_pred", "A_pred"))
+    assert np.isfinite(last) and last < first, (first, last)
+
+
 def test_per_network_train_steps_match_the_joint_pieces(shdr, emor_table):
     """train.py:164-244: `deq_train_step` and `hal_train_step` use exactly the joint step's loss terms, so their gradients
     must equal the joint step's gradients of those networks; `lin_train_step` weighs its terms differently
