@@ -143,8 +143,11 @@ def fp16_roofline(K, fstep, ldr, hdr):
         e1.record()
         c2 = 0 if x2 is None else x2.shape[3]
         d = K._conv_desc_h(x.shape, c2, khw, cout_gemm, stride, None, pad, out_hw)
+        # the dispatch order of csrc/conv_f16.hip (shdr_conv2d_fwd_f16), asked from the library's own predicates
         if lib.shdr_conv2d_patch_ok_f16(ctypes.byref(d)):
             label = "conv_f16_patch_kernel"
+        elif y.dtype == torch.float16 and lib.shdr_conv2d_w3_ok_f16(ctypes.byref(d)):
+            label = "conv_f16_w3_kernel"
         else:
             label = "conv_f16_kernel<%s>" % ("128,128" if cout_gemm % 128 == 0 else "256,64" if cout_gemm % 64 == 0 else
                                               "256,32" if cout_gemm % 32 == 0 else "256,16")
@@ -182,6 +185,105 @@ def fp16_roofline(K, fstep, ldr, hdr):
                          "gflop_per_step": round(tot_fl / 1e9, 1)},
             "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] * 1e3, 2), "launches_per_step": v[2]}
                            for k, v in sorted(agg.items())}}
+
+
+def train_roofline(K, run_step, layers=False):
+    """Per-launch HIP-event timing (on the launch streams) of every conv forward / input-gradient / weight-gradient call inside ONE
+    extra training step: the dominant kernel family by time with the MFMA FLOPs it executes against the peak of its matrix pipe.
+    Labels are the library's plans (asked, not guessed): forward and dgrad by shdr_conv2d_plan_f32 of the (transposed) layer, the
+    weight gradient by the rule of _ops.conv2d_wgrad (Winograd-domain kernel or the MFMA / all-taps family)."""
+    recs = []
+    orig_c, orig_d, orig_w = K.conv2d, K.conv2d_dgrad, K.conv2d_wgrad
+    depth = [0]
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    plan_kernel = {"x3": "conv_x3_kernel", "x3n": "conv_x3n_kernel", "fused": "winograd_fused_kernel", "planes": "winograd_planes",
+                   "mfma": "conv_mfma_dma_kernel", "direct": "conv_direct_kernel"}
+
+    def conv(x, w, bias=None, stride=1, x2=None, **kw):
+        if depth[0] or x.dtype != torch.float32:
+            return orig_c(x, w, bias, stride=stride, x2=x2, **kw)
+        c2 = 0 if x2 is None else x2.shape[3]
+        plan = K.conv2d_plan(tuple(x.shape), tuple(w.shape), c2=c2, stride=stride, x2_scale=kw.get("x2_scale", 1.0),
+                             has_residual=kw.get("residual") is not None, cout_valid=kw.get("cout_valid"))
+        e0, e1 = ev()
+        e0.record()
+        depth[0] += 1
+        try:
+            y = orig_c(x, w, bias, stride=stride, x2=x2, **kw)
+        finally:
+            depth[0] -= 1
+        e1.record()
+        recs.append(("fwd " + plan_kernel[plan], conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
+                     "%dx%dx%d %d+%d->%d k%d s%d" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], c2, w.shape[3], w.shape[0], stride)))
+        return y
+
+    def dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
+        kh, kw_, _, cout = w.shape
+        plan = K.conv2d_plan((x_shape[0], dz.shape[1], dz.shape[2], dz.shape[3]), (kh, kw_, dz.shape[3], x_shape[3])) if stride == 1 else "mfma"
+        e0, e1 = ev()
+        e0.record()
+        depth[0] += 1
+        try:
+            dx = orig_d(dz, w, x_shape, c1, c2, which, stride, x2_scale)
+        finally:
+            depth[0] -= 1
+        e1.record()
+        recs.append(("dgrad " + plan_kernel[plan], 2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * x_shape[3] * dz.shape[3] * kh * kw_, e0, e1,
+                     "%dx%dx%d %d<-%d k%d s%d" % (x_shape[0], x_shape[1], x_shape[2], x_shape[3], dz.shape[3], kh, stride)))
+        return dx
+
+    def wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
+        kh, kw_, cin, cout = w_shape
+        c1, c2 = x.shape[3], (0 if x2 is None else x2.shape[3])
+        wino = (K.WINOGRAD and (kh, kw_) == (3, 3) and stride == 1 and c1 % 32 == 0 and c2 % 32 == 0 and cout % 64 == 0 and c1 % 16 == 0)
+        e0, e1 = ev()
+        e0.record()
+        depth[0] += 1
+        try:
+            dw = orig_w(x, x2, dz, w_shape, stride, x2_scale, out=out)
+        finally:
+            depth[0] -= 1
+        e1.record()
+        if depth[0] == 0:
+            recs.append(("wgrad_winograd_kernel" if wino else "wgrad_mfma / wgrad_alltaps_kernel",
+                         2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * min(cin, {4: 3, 12: 9, 96: 93}.get(cin, cin)) * cout * kh * kw_, e0, e1,
+                         "%dx%dx%d %d+%d->%d k%d s%d" % (x.shape[0], x.shape[1], x.shape[2], c1, c2, cout, kh, stride)))
+        return dw
+
+    K.conv2d, K.conv2d_dgrad, K.conv2d_wgrad = conv, dgrad, wgrad
+    try:
+        run_step()
+        torch.cuda.synchronize()
+    finally:
+        K.conv2d, K.conv2d_dgrad, K.conv2d_wgrad = orig_c, orig_d, orig_w
+    agg = {}
+    for label, fl, e0, e1, desc in recs:
+        a = agg.setdefault(label, [0.0, 0.0, 0])
+        a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        if layers:
+            print("%-36s %-34s %8.3f ms %7.1f TF alg" % (label, desc, e0.elapsed_time(e1), fl / e0.elapsed_time(e1) / 1e9), file=sys.stderr)
+
+    def executed(label, fl):          # MFMA FLOPs the kernel executes, and the peak of the pipe it runs on
+        if "x3" in label:
+            return 3.0 * fl, F16_MFMA_PEAK_TFLOPS
+        if "winograd" in label:
+            return fl / 2.25, F32_MFMA_PEAK_TFLOPS
+        return fl, F32_MFMA_PEAK_TFLOPS
+    dom = max(agg, key=lambda k: agg[k][1])
+    fl, sec, cnt = agg[dom]
+    ex, peak = executed(dom, fl)
+    tot_sec = sum(a[1] for a in agg.values())
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ex / sec / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ex / sec / 1e12 / peak, 4), "launches_per_step": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 2), "executed_gflop_per_launch": round(ex / cnt / 1e9, 2),
+            "traffic": None, "conv_ms_per_step": round(tot_sec * 1e3, 2),
+            "note": "HIP events around each conv forward / dgrad / wgrad call of one extra step (calls on three streams overlap: the "
+                    "per-family times add up to more than the step); executed FLOPs: split-operand kernels x 3 (fp16 pipe), Winograd "
+                    "kernels / 2.25 (fp32 pipe)",
+            "per_kernel": {k: {"executed_tflops": round(executed(k, v[0])[0] / v[1] / 1e12, 1), "frac_of_pipe_peak": round(executed(k, v[0])[0] / v[1] / 1e12 / executed(k, v[0])[1], 4),
+                               "ms_per_step": round(v[1] * 1e3, 2), "launches_per_step": v[2]} for k, v in sorted(agg.items())}}
 
 
 def main():
@@ -250,8 +352,13 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "dtype_note": "fp32 tensors, fp32 results; the wide 3x3 layers, the 7x7/2 stem, the 1x1 layers with K >= 256 (csrc/conv_x3.hip) and the "
                       "narrow U-Net layers (csrc/conv_x3n.hip) compute every fp32 product as three fp16 MFMA products of split operands with "
-                      "fp32 accumulation (3 * 2^-22 per product, held to the exact-fp32 kernels' 1e-5 bar against the float64 oracle); all "
-                      "other layers exact fp32 (fp32 MFMA / FMA); --exact-fp32 runs every layer on the exact kernels",
+                      "fp32 accumulation (3 * 2^-22 per product, held to the exact-fp32 kernels' 1e-5 bar against the float64 oracle).  RANGE: these "
+                      "kernels scale their input by the power of two that brings its range slot (max |x|, written by the producing kernel's "
+                      "epilogue or measured below the C ABI) to [2^10, 2^11) and undo it in the epilogue, both exact: any finite fp32 input "
+                      "range is taken, elements down to 2^-25 of the tensor maximum keep 22 mantissa bits, non-finite inputs give "
+                      "non-finite outputs on their receptive field as the exact kernels do (tests/test_gpu_ops.py::"
+                      "test_split_operand_forward_is_range_safe: 1e5, 1e-7, 1e30, 3e-30, a 7e4 outlier, +-inf).  All other layers exact "
+                      "fp32 (fp32 MFMA / FMA); --exact-fp32 runs every layer on the exact kernels",
         "config": {"workload": "BASELINE configs[2]: full deq+lin+hal inference, batch=%d x %dx%d per GPU, "
                                "fp32 tensors and results, histogram B=4/8/16" % (args.batch, args.size, args.size),
                    "per_gpu_batch": args.batch, "hip_streams_per_gpu": args.streams,
@@ -655,6 +762,11 @@ def main():
             "camera_pipeline_ms_per_batch": round(cam_ms, 3),
             "host_libjpeg_round_trip_ms_per_batch": None if host_jpeg_ms is None else round(host_jpeg_ms, 2),
         }
+        if rank == 0 and world == 1 and not args.no_roofline:          # (the instrumented step all-reduces: N = 1 only)
+            try:
+                result["joint_train"]["roofline"] = train_roofline(K, lambda: step(ds, inv, apply=False), args.layers)
+            except Exception as exc:
+                result["joint_train"]["roofline_error"] = repr(exc)[:300]
 
     # ---- fine-tuning leg (BASELINE configs[4]): the chained deq->lin->hal->ref step of finetune_real_dataset.py on
     #      1024x1024 tiles, fp32 operands vs the fp16-MFMA-operand conv path (fp32 master weights / accumulation) ----
@@ -697,6 +809,11 @@ def main():
                          "images_per_s": round(b * world * args.finetune_steps / fdt, 3),
                          "tflops_algorithmic_per_gpu": round(gflop_img * b * args.finetune_steps / fdt / 1e3, 2),
                          "loss_sum": round(floss, 3), "skipped_steps": fstep.skipped_steps}
+            if prec == "fp32" and rank == 0 and world == 1 and not args.no_roofline:
+                try:
+                    leg[prec]["roofline"] = train_roofline(K, lambda: fstep(f_ldr, f_hdr, apply=False), args.layers)
+                except Exception as exc:
+                    leg[prec]["roofline_error"] = repr(exc)[:300]
             if prec == "fp16" and rank == 0 and world == 1 and not args.no_roofline:      # the instrumented step all-reduces: N = 1 only
                 try:
                     leg[prec]["roofline"] = fp16_roofline(K, fstep, f_ldr, f_hdr)

@@ -444,6 +444,17 @@ int shdr_conv2d_fwd_x3n_ranged_f32(const shdr_conv2d_desc* d, const float* x1, c
                                    const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
                                    const float* x1_range, const float* x2_range, float* y_range, void* stream);
 
+/* Split-operand weight gradient (csrc/wgrad_x3.hip): dW of the fp32 convolution on the fp16 matrix pipe, both operands split --
+ * X 2^Tx = Xh + Xl 2^-11, dZ 2^Tz = Zh + Zl 2^-11, three v_mfma_f32_16x16x32_f16 per operand pair into two fp32 accumulator sets, per-product
+ * error <= 3 * 2^-22 (GradientTape.gradient w.r.t. the Conv2D kernels, joint_training.py:185-186).  shdr_x3_split_planes_f32 writes the two
+ * fp16 planes of a tensor (n % 8 == 0) scaled by the power of two its range slot asks for; shdr_conv2d_wgrad_x3_f32 accumulates
+ * dw [KH*KW][C1+C2][Cout] += x_scale * sum_p X[p + tap] dZ[p] for source `which` from the planes and the SAME two slots (any stride / padding of
+ * the descriptor; channels of the source and Cout multiples of 64: shdr_conv2d_wgrad_x3_ok_f32). */
+int shdr_x3_split_planes_f32(const float* x, int64_t n, const float* range, void* hi, void* lo, void* stream);
+int shdr_conv2d_wgrad_x3_ok_f32(const shdr_conv2d_desc* d, int which);
+int shdr_conv2d_wgrad_x3_f32(const shdr_conv2d_desc* d, const void* xh, const void* xl, int which, const void* zh, const void* zl,
+                             const float* x_range, const float* z_range, float* dw, void* stream);
+
 /* Winograd-domain weight gradient of a 3x3 / stride-1 / SAME convolution (the backward counterpart of the fused Winograd
  * forward): dU[xi] += V[xi]^T Q[xi] over all 2x2 tiles (du: 16*Cx*Cout floats, zeroed by the caller), then
  * dw[3][3][Ct][Cout] (rows ci_off .. ci_off+Cx) += x_scale * G^T dU G.  x [N,H,W,Cx], dz [N,H,W,Cout];

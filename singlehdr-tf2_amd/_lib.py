@@ -56,6 +56,9 @@ SIGNATURES = {
     "shdr_conv2d_fwd_x3_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 9),
     "shdr_conv2d_fwd_x3_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 12),
     "shdr_absmax_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "shdr_x3_split_planes_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "shdr_conv2d_wgrad_x3_ok_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_wgrad_x3_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "shdr_config_reload": (None, []),
     "shdr_conv2d_x3_input_absmax_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "shdr_conv2d_x3n_ok_f32": (c_int, [ctypes.POINTER(ConvDesc)]),

@@ -744,6 +744,21 @@ def _up16(c):
     return (c + 15) // 16 * 16
 
 
+WGRAD_X3_MIN_CH = 128     # conv2d_wgrad: layers with at least this many channels per source and output channels take the split-operand kernel
+
+
+def _split_planes(lib, t, slot):
+    """(high plane, low plane, range slot) of an fp32 tensor for the split-operand weight gradient; the range is measured when the
+    tensor carries no slot (output gradients never do)"""
+    if slot is None:
+        slot = _new_slot(t.device)
+        _lib.check(lib.shdr_absmax_f32(_ptr(t), t.numel(), _ptr(slot), _stream()), "shdr_absmax_f32")
+    hi = torch.empty(t.shape, device=t.device, dtype=torch.float16)
+    lo = torch.empty(t.shape, device=t.device, dtype=torch.float16)
+    _lib.check(lib.shdr_x3_split_planes_f32(_ptr(t), t.numel(), _ptr(slot), _ptr(hi), _ptr(lo), _stream()), "shdr_x3_split_planes_f32")
+    return hi, lo, slot
+
+
 def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
     """dW [kh,kw,C1+C2,Cout] of conv(concat[x, x2_scale*x2], W) given dz = dL/d(conv output).
 
@@ -767,9 +782,26 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
             return torch.cat([dwp[:, :, :c1, :cout], dwp[:, :, c1p:c1p + c2, :cout]], dim=2).contiguous()
         return dwp[:, :, :c1, :cout].contiguous()
     lib = _lib.load()
+    x_in, x2_in = x, x2
     x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
     if x2 is not None:
         _chk(_d(x2), "x2")
+    # Deep k x k layers (>= WGRAD_X3_MIN_CH channels on both sides): the split-operand weight gradient on the fp16 matrix pipe
+    # (csrc/wgrad_x3.hip) -- one split pass per tensor, then three fp16 MFMAs per operand pair.  Measured at batch 32 (tools/wgrad_x3_bench.py,
+    # split passes included) against the Winograd-domain fp32 kernel: 512 -> 512 at 32^2 0.85 -> 0.60 ms, 512 -> 256 at 64^2 1.61 -> 1.06,
+    # 256 -> 256 at 64^2 0.85 -> 0.62, 256 -> 128 at 128^2 1.59 -> 1.27, 128 -> 128 at 128^2 0.78 -> 0.72 (215-290 TFLOP/s in fp32 layer
+    # FLOPs); 1x1 layers do too little arithmetic per element for the two split passes (0.33 -> 0.43 ms at 256 + 256 -> 256) and stay exact
+    if (PRECISION == "fp32" and not EXACT_FP32 and WINOGRAD and kh * kw >= 9 and min(c1, c2 or c1, cout) >= WGRAD_X3_MIN_CH and cin == c1 + c2
+            and cout == dz.shape[3] and x.numel() % 8 == 0 and dz.numel() % 8 == 0 and (x2 is None or x2.numel() % 8 == 0)):
+        d = _conv_desc(x.shape, w_shape, stride, c2, x2_scale, None)
+        if tuple(dz.shape[:3]) == (x.shape[0], d.Ho, d.Wo) and all(int(lib.shdr_conv2d_wgrad_x3_ok_f32(ctypes.byref(d), i)) for i in range(2 if c2 else 1)):
+            dw = out if out is not None else torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
+            zh, zl, zr = _split_planes(lib, dz, None)
+            for src, src_in, which in ((x, x_in, 0),) + (((_d(x2), x2_in, 1),) if x2 is not None else ()):
+                xh, xl, xr = _split_planes(lib, src, _range_of(src_in))
+                _lib.check(lib.shdr_conv2d_wgrad_x3_f32(ctypes.byref(d), _ptr(xh), _ptr(xl), which, _ptr(zh), _ptr(zl), _ptr(xr), _ptr(zr),
+                                                        _ptr(dw), _stream()), "shdr_conv2d_wgrad_x3_f32")
+            return dw
     # (in the reduced-precision modes too for <= 64 channels per source: the exact Winograd-domain kernel is faster there than the
     #  fp16-operand kernel -- 16 x 512^2 x 64 -> 64: 1.77 vs 2.98 ms -- and errs on the accurate side)
     if (WINOGRAD and (PRECISION == "fp32" or max(c1, c2) <= 64) and (kh, kw) == (3, 3) and stride == 1 and c1 % 32 == 0 and c2 % 32 == 0

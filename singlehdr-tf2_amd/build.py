@@ -26,6 +26,7 @@ SOURCES = {
     "conv_f16.hip": [],
     "conv_f16_patch.hip": [],
     "conv_f16_w3.hip": [],
+    "wgrad_x3.hip": [],
     "wgrad_f16.hip": [],
     "wgrad_f16_alltaps.hip": [],
     "elem_f16.hip": ["-ffp-contract=off"],

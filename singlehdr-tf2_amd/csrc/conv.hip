@@ -126,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
         }
         *reinterpret_cast<float4*>(a.y + (size_t)pix * a.y_cs + co) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (a.yr) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[0])), fabsf(v[1])), fabsf(v[2])), fabsf(v[3]));
       } else {  // ragged tail of a zero-padded filter (e.g. Cout = 3): scalar, unaligned-safe
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
       v.z = shdr::act_apply(v.z, a.act2); v.w = shdr::act_apply(v.w, a.act2);
     }
     *reinterpret_cast<float4*>(a.y + pix * a.y_cs + co) = v;
-    if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (a.yr) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v.x)), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
   }
   if (a.yr) conv_range_out(a.yr, ym);
 }

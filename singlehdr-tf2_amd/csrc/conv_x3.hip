@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
         if (a.y && oh + r < a.H && ow < a.W)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
-        if (a.yr && oh + r < a.H) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[r][0]), fabsf(v[r][1]))), fmaxf(fabsf(v[r][2]), fabsf(v[r][3])));
+        if (a.yr && oh + r < a.H) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[r][0])), fabsf(v[r][1])), fabsf(v[r][2])), fabsf(v[r][3]));      // two v_max3_f32
       }
       if (a.yp && a.final) {
         f32x4 m;

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
           // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
           *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
-          if (a.yr) ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          if (a.yr) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[0])), fabsf(v[1])), fabsf(v[2])), fabsf(v[3]));
           acc[mi][ni] = v;                                            // kept for the pooled output below
         } else {
 #pragma unroll

@@ -507,6 +507,53 @@ def test_split_operand_range_slots_travel_with_the_tensors(shdr, monkeypatch):
         assert bool(torch.isfinite(y2).all()) and float((plain - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
 
 
+WGRAD_X3_CASES = [("3x3_128_128", 2, 32, 32, 128, 0, 128, 3, 1), ("3x3_256_128_ragged", 1, 21, 37, 256, 0, 128, 3, 1),
+                  ("3x3_two_sources_scaled", 2, 16, 24, 128, 128, 128, 3, 1), ("3x3_128_192", 1, 24, 24, 128, 0, 192, 3, 1),
+                  ("3x3_stride2_256_128", 2, 32, 32, 256, 0, 128, 3, 2)]
+
+
+@pytest.mark.parametrize("case", WGRAD_X3_CASES, ids=[c[0] for c in WGRAD_X3_CASES])
+def test_split_operand_weight_gradient(shdr, case, monkeypatch):
+    """csrc/wgrad_x3.hip: dW of the deep layers as three fp16 MFMA products of split operands (both operands are activations: X and dZ
+    are split, dZ range-scaled from its measured maximum).  Against the float64 sum (joint_training.py:185-186) at the bar of the
+    exact-fp32 weight-gradient kernels (1e-4 of max |dW|; measured next to the exact plan's error), with unit-scale, TINY (1e-7: output
+    gradients of the joint step reach 3e-8) and heavy-tailed dZ, and huge / tiny activations."""
+    name, n, h, w, c1, c2, cout, k, stride = case
+    K = shdr._ops
+    rng = np.random.default_rng(len(name) * 17 + k)
+    x2s = 1.0 / 255 if c2 else 1.0
+    ho, wo = -(-h // stride), -(-w // stride)
+    import torch_ref as R
+    for label, xmag, zmag, tail in (("unit", 1.0, 1.0, False), ("tiny_dz", 1.0, 1e-7, False), ("heavy_tail_dz", 1.0, 1e-3, True),
+                                    ("big_x_tiny_dz", 3e4, 3e-8, False), ("tiny_x", 1e-6, 1.0, True)):
+        x = f32(rng.normal(size=(n, h, w, c1)) * xmag)
+        x2 = f32(rng.normal(size=(n, h, w, c2)) * xmag * 255.0) if c2 else None
+        dz = rng.normal(size=(n, ho, wo, cout)) * zmag
+        if tail:
+            dz = dz * np.exp(3.0 * rng.normal(size=dz.shape))          # log-normal magnitudes: five decades inside one tensor
+        dz = f32(dz)
+        tw = R.T(np.zeros((k, k, c1 + c2, cout)), True)
+        xin = R.T(x) if c2 == 0 else torch.cat([R.T(x), R.T(x2) * x2s], -1)
+        (R.conv2d(xin, tw, None, stride) * R.T(dz)).sum().backward()
+        ref = tw.grad.numpy()
+
+        def run(exact):
+            monkeypatch.setattr(K, "EXACT_FP32", exact)
+            got = K.conv2d_wgrad(dev(x), None if x2 is None else dev(x2), dev(dz), (k, k, c1 + c2, cout), stride, x2s)
+            monkeypatch.setattr(K, "EXACT_FP32", False)
+            return rel_err(host(got), ref)
+        e_split, e_exact = run(False), run(True)
+        assert e_split <= 1e-4 and e_split <= 4 * e_exact + 1e-6, (label, e_split, e_exact)
+    # the plan: this layer does take the split-operand kernel (and the exact switch does not)
+    lib, d = shdr._lib.load(), K._conv_desc((n, h, w, c1), (k, k, c1 + c2, cout), stride, c2, x2s, None)
+    import ctypes
+    assert lib.shdr_conv2d_wgrad_x3_ok_f32(ctypes.byref(d), 0) == 1 and min(c1, cout) >= K.WGRAD_X3_MIN_CH
+    acc = torch.full((k, k, c1 + c2, cout), 2.0, device="cuda")               # `out=`: accumulates into a flat-gradient view
+    g = K.conv2d_wgrad(dev(x), None if x2 is None else dev(x2), dev(dz), (k, k, c1 + c2, cout), stride, x2s)
+    K.conv2d_wgrad(dev(x), None if x2 is None else dev(x2), dev(dz), (k, k, c1 + c2, cout), stride, x2s, out=acc)
+    assert float((acc - 2.0 - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-6
+
+
 def test_conv2d_x3_dgrad_and_maxpool_pair(shdr, monkeypatch):
     """the input gradient of a wide 3x3 layer takes the split kernel too (shdr_conv2d_dgrad_f32), and conv + MaxPool2D pairs run as
     x3 + pooling; both vs the float64 reference"""

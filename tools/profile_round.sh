@@ -2,7 +2,7 @@
 # Regenerates the judged profiles of a round on the MI355X box:  bash tools/profile_round.sh r01_m
 # (kernel-trace stats of the inference bench and of the training leg, two separate PMC passes for HBM traffic).
 set -e
-TAG=${1:-r01_x}
+TAG=${1:-r03_a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
