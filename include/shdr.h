@@ -198,6 +198,13 @@ int shdr_filter_transform_f32(const float* w, float* wt, int KH, int KW, int Cin
 int64_t shdr_conv2d_dgrad_workspace_bytes_f32(const shdr_conv2d_desc* d, int which);
 int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
                           void* stream);
+/* The same with range slots (see shdr_conv2d_fwd_prepared_ranged_f32): dz_range = upper bound of max |dz| or NULL (then measured where the
+ * split-operand kernels need it: one pass over dz); dx_range = slot that receives max |dx| from the kernel's epilogue, allowed where
+ * shdr_conv2d_dgrad_tracks_range_f32 answers 1 (stride-1 layers on the split-operand / exact MFMA kernels).  A chain conv <- activation <- conv
+ * of a backward pass hands the slot on (|act'(.) dz| <= |dz|) and never measures. */
+int shdr_conv2d_dgrad_tracks_range_f32(const shdr_conv2d_desc* d, int which);
+int shdr_conv2d_dgrad_ranged_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
+                                 const float* dz_range, float* dx_range, void* stream);
 /* workspace a caller must provide for one call of an op: arg = has_residual (CONV2D_FWD), source (CONV2D_DGRAD,
  * CONV2D_WGRAD_WINOGRAD: the dU scratch), channel count (BATCHNORM: the double-precision partial sums) */
 enum { SHDR_OP_CONV2D_FWD = 0, SHDR_OP_CONV2D_DGRAD = 1, SHDR_OP_CONV2D_WGRAD_WINOGRAD = 2, SHDR_OP_BATCHNORM = 3,

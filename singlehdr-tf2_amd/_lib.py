@@ -82,6 +82,8 @@ SIGNATURES = {
     "shdr_conv2d_fwd_prepared_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 14),
     "shdr_conv2d_dgrad_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_dgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "shdr_conv2d_dgrad_tracks_range_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "shdr_conv2d_dgrad_ranged_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "shdr_workspace_bytes": (c_i64, [c_int, ctypes.POINTER(ConvDesc), c_int]),
     "shdr_soft_hist_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr]),
     "shdr_conv2d_wgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_ptr, c_int, c_ptr, c_ptr, c_ptr]),

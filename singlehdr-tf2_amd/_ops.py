@@ -166,7 +166,9 @@ def _range_of(t):
         return None
     r = getattr(t, "_shdr_range", None)
     if r is not None:
-        return r
+        # a slot describes the tensor as it was written: an in-place update since then (autograd accumulating a second gradient
+        # into the same buffer) voids it -- torch bumps the version counter on every in-place op
+        return r if getattr(t, "_shdr_range_ver", t._version) == t._version else None
     b = getattr(t, "_shdr_bound", None)
     if b is None:
         return None
@@ -177,11 +179,18 @@ def _range_of(t):
     return slot
 
 
+def _set_range(t, slot):
+    t._shdr_range = slot
+    t._shdr_range_ver = t._version
+    return t
+
+
 def _carry_range(y, x, factor=None):
-    """y is bounded by x's bound (pooling, convex resampling, channel permutation, clipping of an already bounded tensor)"""
-    r = getattr(x, "_shdr_range", None)
+    """y is bounded by x's bound (pooling, convex resampling, channel permutation, clipping of an already bounded tensor, the
+    derivative of an activation applied to a gradient)"""
+    r = _range_of(x) if getattr(x, "_shdr_range", None) is not None else None
     if r is not None:
-        y._shdr_range = r
+        _set_range(y, r)
     b = getattr(x, "_shdr_bound", None)
     if b is not None:
         y._shdr_bound = b
@@ -200,7 +209,7 @@ def absmax_slot(x):
     xd = _chk(_d(x), "x")
     slot = _new_slot(xd.device)
     _lib.check(lib.shdr_absmax_f32(_ptr(xd), xd.numel(), _ptr(slot), _stream()), "shdr_absmax_f32")
-    x._shdr_range = slot
+    _set_range(x, slot)
     return slot
 
 
@@ -343,7 +352,7 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     if yr is not None:
         for t in (out, yp):
             if t is not None:
-                t._shdr_range = yr         # (the pooled copy is bounded by the same maximum)
+                _set_range(t, yr)          # (the pooled copy is bounded by the same maximum)
     if pool == "only":
         return yp
     return (out, yp) if pool else out
@@ -449,6 +458,7 @@ def conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
     dz = dL/d(conv output) [N,Ho,Wo,cout_valid]: ONE library call (shdr_conv2d_dgrad_f32: filter flip / slice / zero-padding,
     Winograd where the transposed layer qualifies, 1x1 / 2 on the coarse grid, polyphase form for general stride 2)."""
     lib = _lib.load()
+    dz_in = dz
     dz, w = _chk(_d(dz), "dz"), _chk(_d(w), "w")
     n, h, wd, cx = x_shape
     kh, kw, cin, cout = w.shape
@@ -469,8 +479,13 @@ def conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
         raise ValueError("conv2d_dgrad: bad descriptor")
     ws = torch.empty(max(nws, 16), device=dz.device, dtype=torch.uint8)
     dx = torch.empty(tuple(x_shape), device=dz.device, dtype=torch.float32)
-    _lib.check(lib.shdr_conv2d_dgrad_f32(ctypes.byref(d), int(which), _ptr(dz), _ptr(w), _ptr(dx), _ptr(ws), _stream()),
-               "shdr_conv2d_dgrad_f32")
+    # range slots (a chain conv <- activation <- conv of a backward pass never measures: |act' dz| <= |dz|, _carry_range)
+    zr = _range_of(dz_in)
+    xr = _new_slot(dz.device) if int(lib.shdr_conv2d_dgrad_tracks_range_f32(ctypes.byref(d), int(which))) else None
+    _lib.check(lib.shdr_conv2d_dgrad_ranged_f32(ctypes.byref(d), int(which), _ptr(dz), _ptr(w), _ptr(dx), _ptr(ws), _ptr(zr), _ptr(xr), _stream()),
+               "shdr_conv2d_dgrad_ranged_f32")
+    if xr is not None:
+        _set_range(dx, xr)
     return dx
 
 
@@ -782,7 +797,7 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
             return torch.cat([dwp[:, :, :c1, :cout], dwp[:, :, c1p:c1p + c2, :cout]], dim=2).contiguous()
         return dwp[:, :, :c1, :cout].contiguous()
     lib = _lib.load()
-    x_in, x2_in = x, x2
+    x_in, x2_in, dz_in = x, x2, dz
     x, dz = _chk(_d(x), "x"), _chk(_d(dz), "dz")
     if x2 is not None:
         _chk(_d(x2), "x2")
@@ -796,7 +811,8 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
         d = _conv_desc(x.shape, w_shape, stride, c2, x2_scale, None)
         if tuple(dz.shape[:3]) == (x.shape[0], d.Ho, d.Wo) and all(int(lib.shdr_conv2d_wgrad_x3_ok_f32(ctypes.byref(d), i)) for i in range(2 if c2 else 1)):
             dw = out if out is not None else torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32)
-            zh, zl, zr = _split_planes(lib, dz, None)
+            zh, zl, zr = _split_planes(lib, dz, _range_of(dz_in))
+            _set_range(dz_in, zr)           # the input gradient of the same layer (called next) takes the slot instead of measuring again
             for src, src_in, which in ((x, x_in, 0),) + (((_d(x2), x2_in, 1),) if x2 is not None else ()):
                 xh, xl, xr = _split_planes(lib, src, _range_of(src_in))
                 _lib.check(lib.shdr_conv2d_wgrad_x3_f32(ctypes.byref(d), _ptr(xh), _ptr(xl), which, _ptr(zh), _ptr(zl), _ptr(xr), _ptr(zr),
@@ -859,6 +875,7 @@ def act_bwd_bias(dy, y, act, out=None):
     count allows (C / 4 a power of two), the act_bwd + bias_grad pair otherwise.  `out`: gradient buffer to accumulate db into."""
     if _is_h(dy):
         return act_bwd_bias_h(dy, y, act, True, out)
+    dy_in = dy
     dy = _chk(_d(dy), "dy")
     c = dy.shape[-1]
     q = c // 4
@@ -875,6 +892,8 @@ def act_bwd_bias(dy, y, act, out=None):
         yp, zp = _ptr(y), _ptr(dz)
     _lib.check(lib.shdr_act_bwd_bias_f32(_ptr(dy), yp, zp, _ptr(db), _ptr(_bias_ws(c, dy.device)), dy.numel() // c, c, act, _stream()),
                "shdr_act_bwd_bias_f32")
+    if dz is not dy:
+        _carry_range(dz, dy_in)         # |act'(y)| <= 1
     return dz, db
 
 
@@ -882,18 +901,20 @@ def act_bwd(dy, y, act):
     if _is_h(dy):
         return act_bwd_bias_h(dy, y, act, False)[0]
     lib = _lib.load()
+    dy_in = dy
     dy, y = _chk(_d(dy), "dy"), _chk(_d(y), "y")
     dx = torch.empty_like(dy)
     _lib.check(lib.shdr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), act, _stream()), "shdr_act_bwd_f32")
-    return dx
+    return _carry_range(dx, dy_in)     # |act'(y)| <= 1 for relu / leaky relu / tanh
 
 
 def clip_bwd(dy, x, lo, hi):
     lib = _lib.load()
+    dy_in = dy
     dy, x = _chk(_d(dy), "dy"), _chk(_d(x), "x")
     dx = torch.empty_like(dy)
     _lib.check(lib.shdr_clip_bwd_f32(_ptr(dy), _ptr(x), _ptr(dx), dy.numel(), float(lo), float(hi), _stream()), "shdr_clip_bwd_f32")
-    return dx
+    return _carry_range(dx, dy_in)
 
 
 def add(a, b, relu=False):

@@ -323,8 +323,23 @@ extern "C" int64_t shdr_conv2d_dgrad_workspace_bytes_f32(const shdr_conv2d_desc*
   return (int64_t)dgrad_geom(d, which).total;
 }
 
+// 1 if the input-gradient launch of this layer writes the range slot of dx from its own epilogue (stride-1 layers on the split-operand
+// and exact MFMA kernels): a host then hands a slot to shdr_conv2d_dgrad_ranged_f32 and passes it on to the consumer of dx
+extern "C" int shdr_conv2d_dgrad_tracks_range_f32(const shdr_conv2d_desc* d, int which) {
+  if (!d || (which != 0 && !(which == 1 && d->C2 > 0)) || d->stride != 1) return 0;
+  const DgradGeom g = dgrad_geom(d, which);
+  return (g.x3n || g.x3 || !g.wino) ? 1 : 0;
+}
+
 extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
                                      void* stream) {
+  return shdr_conv2d_dgrad_ranged_f32(d, which, dz, w, dx, workspace, nullptr, nullptr, stream);
+}
+
+// The same with range slots (conv_x3.hip "Range"): dz_range = upper bound of max |dz| (NULL: measured where a split-operand kernel needs
+// it -- output gradients sit far below the fp16 range), dx_range (only where shdr_conv2d_dgrad_tracks_range_f32) = slot that receives max |dx|.
+extern "C" int shdr_conv2d_dgrad_ranged_f32(const shdr_conv2d_desc* d, int which, const float* dz, const float* w, float* dx, void* workspace,
+                                            const float* dz_range, float* dx_range, void* stream) {
   SHDR_REQUIRE(d && dz && w && dx && workspace, SHDR_E_NULL, "conv2d_dgrad: null pointer");
   SHDR_REQUIRE(which == 0 || (which == 1 && d->C2 > 0), SHDR_E_SHAPE, "conv2d_dgrad: `which` selects x1 (0) or x2 (1)");
   SHDR_REQUIRE(d->stride == 1 || d->stride == 2, SHDR_E_SHAPE, "conv2d_dgrad: stride %d is not built", d->stride);
@@ -354,27 +369,33 @@ extern "C" int shdr_conv2d_dgrad_f32(const shdr_conv2d_desc* d, int which, const
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.algo = SHDR_ALGO_AUTO;
       if (int rc = shdr_conv2d_x3n_prepare_filter_f32(&c, wt, u, stream)) return rc;
-      if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;       // header slot 2, as the wide kernel
-      c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
-      return shdr_conv2d_fwd_x3n_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, nullptr, dx, nullptr, stream);
+      if (!dz_range) {
+        if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;     // header slot 2, as the wide kernel
+        c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
+      }
+      return shdr_conv2d_fwd_x3n_ranged_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, nullptr, dx, nullptr, dz_range, nullptr, dx_range, stream);
     }
     if (g.x3) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
       if (int rc = shdr_conv2d_x3_prepare_filter_f32(&c, wt, u, stream)) return rc;
       // output gradients sit far below the fp16 range (max |dz| 3e-8 ... 2e-2 in the joint step): scaled in the kernel by a power of two
-      if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;
-      c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
-      return shdr_conv2d_fwd_x3_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, stream);
+      if (!dz_range) {
+        if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;
+        c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
+      }
+      return shdr_conv2d_fwd_x3_ranged_f32(&c, dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, dz_range, nullptr, dx_range, stream);
     }
     if (g.wino) {
+      SHDR_REQUIRE(!dx_range, SHDR_E_SHAPE, "conv2d_dgrad: the Winograd plan does not track dx_range (shdr_conv2d_dgrad_tracks_range_f32)");
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       if (int rc = shdr_winograd_filter_packed_f32(wt, u, g.CZ, g.CC, stream)) return rc;
       return shdr_conv2d_winograd_fused2_f32(dzp, nullptr, u, nullptr, nullptr, nullptr, dx, nullptr, c.N, c.H, c.W, g.CZ, 0, g.CC, SHDR_ACT_NONE,
                                              SHDR_ACT_NONE, stream);
     }
-    return shdr_conv2d_fwd_f32(&c, dzp, nullptr, wt, nullptr, nullptr, nullptr, nullptr, dx, stream);
+    return shdr_conv2d_fwd_yrange_f32(&c, dzp, nullptr, wt, nullptr, nullptr, nullptr, nullptr, dx, dx_range, stream);
   }
+  SHDR_REQUIRE(!dx_range, SHDR_E_SHAPE, "conv2d_dgrad: dx_range is written by the stride-1 kernels only (shdr_conv2d_dgrad_tracks_range_f32)");
   // ---- stride 2: the conv output lands on every second pixel of dx (strided placement) -----------------------------------------
   c.y_pix_stride = 2; c.y_H = d->H; c.y_W = d->W;
   const size_t dx_bytes = (size_t)d->N * d->H * d->W * g.c_count * sizeof(float);
