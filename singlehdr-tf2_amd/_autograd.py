@@ -60,6 +60,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.meta = (stride, x2_scale, act1, bias is not None)
         ctx.bias_ref = bias             # (not a saved tensor: only its .grad buffer is looked up in backward)
         ctx.prec = K.PRECISION          # the backward kernels run at the precision of the forward
+        # the range slots of the sources (K: "range slots"): saved tensors come back as fresh objects without their attributes, and the
+        # split-operand weight gradient would measure max |x| again
+        ctx.ranges = (K._range_of(x), K._range_of(x2)) if x.dtype == torch.float32 else (None, None)
         return y
 
     @staticmethod
@@ -70,6 +73,9 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dy):
         x, x2, w, y = ctx.saved_tensors
+        for t, r in zip((x, x2), ctx.ranges):
+            if t is not None and r is not None:
+                K._set_range(t, r)
         stride, x2_scale, act1, has_bias = ctx.meta
         dy = _c(dy)
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[:4]

@@ -946,7 +946,7 @@ def mark(x, callback):
     it in the forward has been enqueued): where the data-parallel steps launch a gradient bucket's all-reduce"""
     if callback is None or not _needs_grad(x):
         return x
-    return AUTOGRAD.mark(x, callback)
+    return _carry_range(AUTOGRAD.mark(x, callback), x)
 
 
 def fork(x, n=2):
@@ -954,7 +954,7 @@ def fork(x, n=2):
     gradients are summed by the add kernel of this library; without a tape it is x itself, n times"""
     if not _needs_grad(x):
         return (x,) * n
-    return AUTOGRAD.fork(x, n)
+    return tuple(_carry_range(t, x) for t in AUTOGRAD.fork(x, n))      # (the aliases are new tensor objects: hand the range slot on)
 
 
 def affine_act(x, scale=None, shift=None, residual=None, act=ACT_NONE):

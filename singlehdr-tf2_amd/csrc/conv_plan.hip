@@ -12,6 +12,9 @@
 
 #include "shdr_internal.h"
 
+extern "C" int shdr_conv2d_x3_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream);
+extern "C" int shdr_conv2d_x3n_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream);
+
 namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -60,9 +63,13 @@ __global__ __launch_bounds__(256) void fold_x2_scale_kernel(const float* __restr
 // dgrad filter with slicing and zero padding in one pass:
 //   wt[kh][kw][co][ci] = scale * w[KH-1-kh][KW-1-kw][c_begin + ci][co]   for co < cout_real, ci < c_count, zero for the padded rest
 //   (co < CZ = channels per pixel of the dz tensor the conv will read, ci < CC = output channels of that conv)
+//   maxslot (optional): receives max |wt| (bits, atomicMax; zeroed by the caller) -- the header slot of the split-operand filter that is
+//   packed from wt next, which then needs no absmax launch of its own
 __global__ __launch_bounds__(256) void dgrad_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int Ct, int Cout,
-                                                           int cout_real, int c_begin, int c_count, int CZ, int CC, float scale) {
+                                                           int cout_real, int c_begin, int c_count, int CZ, int CC, float scale,
+                                                           unsigned* __restrict__ maxslot) {
   const long total = (long)KH * KW * CZ * CC;
+  float m = 0.f;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int ci = (int)(e % CC);
     long t = e / CC;
@@ -72,6 +79,12 @@ __global__ __launch_bounds__(256) void dgrad_filter_kernel(const float* __restri
     float v = 0.0f;
     if (ci < c_count && co < cout_real) v = scale * w[(((long)(KH - 1 - kh) * KW + (KW - 1 - kw)) * Ct + c_begin + ci) * Cout + co];
     wt[e] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  if (maxslot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxslot, __float_as_uint(m));
   }
 }
 
@@ -351,8 +364,13 @@ extern "C" int shdr_conv2d_dgrad_ranged_f32(const shdr_conv2d_desc* d, int which
   hipStream_t st = S(stream);
   const int Ct = d->C1 + d->C2;
   const float scale = which ? d->x2_scale : 1.0f;
-  hipLaunchKernelGGL(dgrad_filter_kernel, dim3(shdr::stream_grid((long)d->KH * d->KW * g.CZ * g.CC)), dim3(256), 0, st, w, wt, d->KH, d->KW, Ct,
-                     d->Cout, g.cout_real, g.c_begin, g.c_count, g.CZ, g.CC, scale);
+  // the split-operand plans pack wt next: its maximum comes out of this pass (header slot 0 of the packed filter)
+  unsigned* maxslot = (d->stride == 1 && (g.x3n || g.x3)) ? reinterpret_cast<unsigned*>(ws + g.off_u) : nullptr;
+  if (maxslot && hipMemsetAsync(maxslot, 0, 64, st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_dgrad: memset failed");
+  long fgrid = shdr::stream_grid((long)d->KH * d->KW * g.CZ * g.CC);
+  if (maxslot && fgrid > 256) fgrid = 256;                 // (every wave ends in an atomicMax on one address)
+  hipLaunchKernelGGL(dgrad_filter_kernel, dim3((unsigned)fgrid), dim3(256), 0, st, w, wt, d->KH, d->KW, Ct,
+                     d->Cout, g.cout_real, g.c_begin, g.c_count, g.CZ, g.CC, scale, maxslot);
   if (int rc = shdr::check_launch("dgrad_filter")) return rc;
   const float* dzp = dz;
   if (g.pad_dz) {
@@ -368,7 +386,7 @@ extern "C" int shdr_conv2d_dgrad_ranged_f32(const shdr_conv2d_desc* d, int which
     if (g.x3n) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.algo = SHDR_ALGO_AUTO;
-      if (int rc = shdr_conv2d_x3n_prepare_filter_f32(&c, wt, u, stream)) return rc;
+      if (int rc = shdr_conv2d_x3n_prepare_filter_premax_f32(&c, wt, u, 1, stream)) return rc;
       if (!dz_range) {
         if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;     // header slot 2, as the wide kernel
         c.prologue = SHDR_PROLOGUE_RANGE_SCALE;
@@ -378,7 +396,7 @@ extern "C" int shdr_conv2d_dgrad_ranged_f32(const shdr_conv2d_desc* d, int which
     if (g.x3) {
       float* u = reinterpret_cast<float*>(ws + g.off_u);
       c.cout_valid = g.CC; c.algo = SHDR_ALGO_AUTO;
-      if (int rc = shdr_conv2d_x3_prepare_filter_f32(&c, wt, u, stream)) return rc;
+      if (int rc = shdr_conv2d_x3_prepare_filter_premax_f32(&c, wt, u, 1, stream)) return rc;
       // output gradients sit far below the fp16 range (max |dz| 3e-8 ... 2e-2 in the joint step): scaled in the kernel by a power of two
       if (!dz_range) {
         if (int rc = shdr_conv2d_x3_input_absmax_f32(dzp, (int64_t)c.N * c.H * c.W * c.C1, u, stream)) return rc;

@@ -583,7 +583,13 @@ extern "C" int64_t shdr_conv2d_x3_filter_elems_f32(const shdr_conv2d_desc* d) {
   return total;
 }
 
+// premax: header slot 0 of the (single) phase already holds max |w| (written by the kernel that produced w: the input gradient's filter
+// transform) -- no memset, no absmax launch
+extern "C" int shdr_conv2d_x3_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream);
 extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream) {
+  return shdr_conv2d_x3_prepare_filter_premax_f32(d, w, prepared, 0, stream);
+}
+extern "C" int shdr_conv2d_x3_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream) {
   SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "conv2d_x3_prepare_filter: null pointer");
   const int Ct = d->C1 + d->C2;
   SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && d->C1 % 32 == 0 && d->Cout > 0 && d->Cout % 64 == 0, SHDR_E_SHAPE,
@@ -595,11 +601,14 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
   const int n = x3_phases(d, ph);
   const long nw = (long)d->KH * d->KW * Ct * d->Cout;
   float* out = prepared;
+  SHDR_REQUIRE(!premax || n == 1, SHDR_E_SHAPE, "conv2d_x3_prepare_filter: premax is for single-phase (stride-1) layers");
   for (int i = 0; i < n; ++i) {
-    if (hipMemsetAsync(out, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
-    // <= 64 blocks: every wave ends with an atomicMax on ONE address (2048 blocks took 50 us on a 9 MB filter, this takes 6)
-    const int gmax = shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64;
-    hipLaunchKernelGGL(x3_absmax_kernel, dim3(gmax), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
+    if (!premax) {
+      if (hipMemsetAsync(out, 0, X3_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3_prepare_filter: memset");
+      // <= 64 blocks: every wave ends with an atomicMax on ONE address (2048 blocks took 50 us on a 9 MB filter, this takes 6)
+      const int gmax = shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64;
+      hipLaunchKernelGGL(x3_absmax_kernel, dim3(gmax), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
+    }
     const long np = (long)ph[i].th * ph[i].tw * Ct * d->Cout;
     hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
                        d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);

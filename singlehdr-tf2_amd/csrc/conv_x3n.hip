@@ -493,16 +493,23 @@ extern "C" int64_t shdr_conv2d_x3n_filter_elems_f32(const shdr_conv2d_desc* d) {
 }
 
 // w: HWIO [KH][KW][C1 + C2][cout_w] with cout_w = the filter tensor's channel count (>= cout_valid; the desc's Cout may be its padding)
+extern "C" int shdr_conv2d_x3n_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream);
 extern "C" int shdr_conv2d_x3n_prepare_filter_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, void* stream) {
+  return shdr_conv2d_x3n_prepare_filter_premax_f32(d, w, prepared, 0, stream);
+}
+// premax: header slot 0 already holds max |w| (conv_x3.hip: shdr_conv2d_x3_prepare_filter_premax_f32)
+extern "C" int shdr_conv2d_x3n_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream) {
   SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "conv2d_x3n_prepare_filter: null pointer");
   SHDR_REQUIRE(shdr::aligned16(prepared), SHDR_E_ALIGN, "conv2d_x3n_prepare_filter: prepared must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int ct = ct_of(d), Creal = d->C1 + d->C2, ntaps = d->KH * d->KW, ns = (ntaps * ct + 31) / 32;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
-  if (hipMemsetAsync(prepared, 0, XN_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3n_prepare_filter: memset");
   const long nw = (long)ntaps * Creal * d->Cout;             // the filter tensor handed over has the desc's (padded) Cout columns
-  hipLaunchKernelGGL(x3n_absmax_kernel, dim3(shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64), dim3(256), 0, st, w, nw,
-                     reinterpret_cast<unsigned*>(prepared));
+  if (!premax) {
+    if (hipMemsetAsync(prepared, 0, XN_HEADER_FLOATS * sizeof(float), st) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_x3n_prepare_filter: memset");
+    hipLaunchKernelGGL(x3n_absmax_kernel, dim3(shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64), dim3(256), 0, st, w, nw,
+                       reinterpret_cast<unsigned*>(prepared));
+  }
   hipLaunchKernelGGL(x3n_pack_kernel, dim3(shdr::stream_grid((long)ns * d->Cout * 32)), dim3(256), 0, st, w, prepared,
                      reinterpret_cast<_Float16*>(prepared + XN_HEADER_FLOATS), ntaps, ct, d->C1, Creal, cv, d->Cout, d->Cout, ns,
                      d->C2 > 0 ? d->x2_scale : 1.0f);
