@@ -117,12 +117,13 @@ __device__ __forceinline__ void x3_split4(const f32x4 v, float xs, unsigned (&h)
 }
 // max |y| of a wave -> the range slot: one no-return atomicMax per wave, and only when the wave's maximum exceeds what the slot already
 // holds (an agent-scope load: atomics execute at the memory side) -- after the first round of blocks almost no wave issues one
-__device__ __forceinline__ void x3_range_out(unsigned* slot, float m, int lane) {
+// `seen` = the slot's value loaded at the START of the epilogue (the load's round trip to the memory side runs under the stores)
+__device__ __forceinline__ void x3_range_out(unsigned* slot, float m, int lane, unsigned seen) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if (lane == 0) {
     const unsigned b = __float_as_uint(m);
-    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+    if (b > seen) atomicMax(slot, b);
   }
 }
 
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   // out one at a time
   // (the offsets pass through an opaque asm so that the loads are not hoisted above the tap loop, where their registers would be live
   //  for the whole kernel)
+  const unsigned yr_seen = (a.yr && a.final) ? __hip_atomic_load(a.yr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   int ep0 = n0;
   asm volatile("" : "+s"(ep0));
   f32x4 bias_r[NT], scale_r[NT], shift_r[NT];
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       }
     }
   }
-  if (a.yr && a.final) x3_range_out(a.yr, ow < a.W ? ym : 0.0f, lane);      // (a pooled output is bounded by the same maximum)
+  if (a.yr && a.final) x3_range_out(a.yr, ow < a.W ? ym : 0.0f, lane, yr_seen);      // (a pooled output is bounded by the same maximum)
 }
 
 #undef patch_h
