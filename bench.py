@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_{32x32x2,16x16x4}_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
-TRAFFIC_FILE = "r02_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_traffic.json")) else "r01_traffic.json"
+TRAFFIC_FILE = next((f for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_traffic.json")
 
 
 def parse_args():

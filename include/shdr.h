@@ -311,6 +311,10 @@ int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float* var, float
 int shdr_bn_train_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
                             const float* beta, float* y, int64_t npix, int C, float eps, int relu,
                             void* stream);
+/* the same; y_range (or NULL) = range slot that receives max |y| (see shdr_conv2d_fwd_prepared_ranged_f32): the consumer of a
+ * training-mode BatchNorm output is usually a split-operand convolution, which then need not measure its input */
+int shdr_bn_train_apply_ranged_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y,
+                                   int64_t npix, int C, float eps, int relu, float* y_range, void* stream);
 /* y_relu != NULL: the forward applied relu after BN; dy is masked by y_relu > 0 first. */
 int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean,
                     const float* var, const float* gamma, double* ws, float* dgamma, float* dbeta,

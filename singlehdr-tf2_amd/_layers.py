@@ -96,7 +96,10 @@ class Layer:
             child._drop_derived()
 
     def __call__(self, *args, **kwargs):
-        return self.call(*args, **kwargs)
+        if K._RANGE_SCOPES:
+            return self.call(*args, **kwargs)
+        with K.range_scope():          # a model called on its own: its range slots come out of one zeroed slab (K: "range slots")
+            return self.call(*args, **kwargs)
 
 
 def _glorot_uniform(shape, fan_in, fan_out, device):

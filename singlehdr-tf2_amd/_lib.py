@@ -118,6 +118,7 @@ SIGNATURES = {
     "shdr_upsample_zero2_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_bn_stats_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_ptr]),
     "shdr_bn_train_apply_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr]),
+    "shdr_bn_train_apply_ranged_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr, c_ptr]),
     "shdr_bn_bwd_f32": (c_int, [c_ptr] * 10 + [c_i64, c_int, c_f32, c_ptr]),
     "shdr_invcrf_decode_bwd_f32": (c_int, [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr]),
     "shdr_increase_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),

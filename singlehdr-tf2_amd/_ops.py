@@ -5,6 +5,7 @@ NHWC float32 CUDA(HIP) tensors, allocates the output with torch and launches the
 hand-written gfx950 kernel on torch's current stream through ctypes.  There is
 no fallback path: CPU tensors or a missing library raise.
 """
+import collections
 import ctypes
 
 import torch
@@ -152,6 +153,9 @@ class range_scope:
             self._slab, self._n = torch.zeros(self.SLOTS, device=device, dtype=torch.float32), 0
         self._n += 1
         return self._slab[self._n - 1:self._n]
+
+
+RANGE_MISSES = collections.Counter()      # split-operand layers whose input arrived without a range (diagnostic: each costs one pass over x)
 
 
 def _new_slot(device):
@@ -332,6 +336,8 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
     split = plan in (4, 5)             # SHDR_PLAN_X3 / X3N: the input is scaled by its range, the epilogue tracks the output's
     xr1 = _range_of(x_in) if split else None
     xr2 = _range_of(x2_in) if (split and x2 is not None) else None
+    if split and (xr1 is None or (x2 is not None and xr2 is None)):
+        RANGE_MISSES[(tuple(x.shape), None if x2 is None else tuple(x2.shape), tuple(w.shape))] += 1     # measured below the ABI
     ws = None
     nws = int(lib.shdr_conv2d_workspace_bytes_f32(ctypes.byref(d), has_res))
     if nws > 256 or (nws > 0 and (not split or xr1 is None or (x2 is not None and xr2 is None))):
@@ -709,6 +715,7 @@ def pack3(srcs, out_channels=None, dtype=torch.float32):
     if _needs_grad(*srcs):
         return AUTOGRAD.pack3(list(srcs), out_channels, dtype)
     lib = _lib.load()
+    srcs_in = list(srcs)
     srcs = [_pix3(s, "src%d" % i)[0] for i, s in enumerate(srcs)]
     n = len(srcs)
     if not 1 <= n <= 4:
@@ -723,6 +730,11 @@ def pack3(srcs, out_channels=None, dtype=torch.float32):
         return y
     _lib.check(lib.shdr_pack3_fwd_f32(p[0], p[1], p[2], p[3], n, _ptr(y), oc, srcs[0].numel() // 3,
                                       _stream()), "shdr_pack3_fwd_f32")
+    if n == 1:                               # a channel-padded copy: the same range
+        return _carry_range(y, srcs_in[0])
+    bounds = [getattr(t, "_shdr_bound", None) for t in srcs_in]
+    if all(b is not None for b in bounds):   # (device-side slots of several sources are not merged: measured by the consumer)
+        set_bound(y, max(bounds))
     return y
 
 
@@ -1048,9 +1060,14 @@ def bn_train_apply(x, mean, var, gamma, beta, eps, relu):
     x = _chkh(_d(x), "x") if h else _chk(_d(x), "x")
     c = x.shape[-1]
     y = torch.empty_like(x)
-    fn = "shdr_bn_train_apply_f16" if h else "shdr_bn_train_apply_f32"
-    _lib.check(getattr(lib, fn)(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
-                                x.numel() // c, c, float(eps), int(bool(relu)), _stream()), fn)
+    if not h:                          # fp32: the kernel also writes the range slot of y (its consumer is usually a split-operand conv)
+        yr = _new_slot(x.device)
+        _lib.check(lib.shdr_bn_train_apply_ranged_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
+                                                      x.numel() // c, c, float(eps), int(bool(relu)), _ptr(yr), _stream()),
+                   "shdr_bn_train_apply_ranged_f32")
+        return _set_range(y, yr)
+    _lib.check(lib.shdr_bn_train_apply_f16(_ptr(x), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(_d(beta)), _ptr(y),
+                                           x.numel() // c, c, float(eps), int(bool(relu)), _stream()), "shdr_bn_train_apply_f16")
     return y
 
 
@@ -1555,7 +1572,7 @@ def u8_to_unit(img_u8, reverse_channels=False):
     y = torch.empty(img_u8.shape, device=img_u8.device, dtype=torch.float32)
     _lib.check(lib.shdr_u8_to_unit_f32(_ptr(img_u8), _ptr(y), img_u8.numel() // 3, int(reverse_channels), _stream()),
                "shdr_u8_to_unit_f32")
-    return y
+    return set_bound(y, 1.0)
 
 
 def resize_cubic(x, out_hw):

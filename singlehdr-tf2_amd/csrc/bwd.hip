@@ -448,12 +448,25 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restr
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ var, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
-                                                             long total, int C, float eps, int relu) {
+                                                             long total, int C, float eps, int relu, unsigned* __restrict__ yr) {
+  float ym = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     float v = (x[i] - mean[c]) * rsqrtf(var[c] + eps) * gamma[c] + beta[c];
     if (relu) v = fmaxf(v, 0.f);
     y[i] = v;
+    ym = fmaxf(ym, fabsf(v));
+  }
+  if (yr) {                                                    // range slot of y (conv_x3.hip "Range"): the consumer is usually a split-operand conv
+    __shared__ float part[4];                                  // one filtered atomicMax per BLOCK (a grid of 2048 blocks ends on one address)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ym = fmaxf(ym, __shfl_xor(ym, off, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ym;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned b = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+      if (b > __hip_atomic_load(yr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(yr, b);
+    }
   }
 }
 
@@ -918,13 +931,17 @@ extern "C" int shdr_bn_stats_f32(const float* x, double* ws, float* mean, float*
                      (long)npix, C, momentum);
   return shdr::check_launch("bn_stats");
 }
-extern "C" int shdr_bn_train_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
-                                       const float* beta, float* y, int64_t npix, int C, float eps, int relu, void* stream) {
+extern "C" int shdr_bn_train_apply_ranged_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                                              float* y, int64_t npix, int C, float eps, int relu, float* y_range, void* stream) {
   SHDR_REQUIRE(x && mean && var && gamma && beta && y, SHDR_E_NULL, "bn_train_apply: null pointer");
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_train_apply: bad shape");
   hipLaunchKernelGGL(bn_train_apply_kernel, dim3(shdr::stream_grid(npix * C)), dim3(256), 0, S(stream), x, mean, var,
-                     gamma, beta, y, (long)npix * C, C, eps, relu);
+                     gamma, beta, y, (long)npix * C, C, eps, relu, reinterpret_cast<unsigned*>(y_range));
   return shdr::check_launch("bn_train_apply");
+}
+extern "C" int shdr_bn_train_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
+                                       const float* beta, float* y, int64_t npix, int C, float eps, int relu, void* stream) {
+  return shdr_bn_train_apply_ranged_f32(x, mean, var, gamma, beta, y, npix, C, eps, relu, nullptr, stream);
 }
 extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean, const float* var,
                                const float* gamma, double* ws, float* dgamma, float* dbeta, float* dx, int64_t npix,

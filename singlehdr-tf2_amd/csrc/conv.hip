@@ -56,14 +56,30 @@ struct ConvArgs {
   unsigned* yr;          // range slot of the output (conv_x3.hip "Range"): atomicMax of max |y| over the stored values, or null
 };
 
-// max |y| of a wave -> the range slot: one atomicMax per wave, only if it exceeds what the slot holds (agent-scope load)
-__device__ __forceinline__ void conv_range_out(unsigned* slot, float m) {
+// max |y| -> the range slot, only if it exceeds what the slot holds (agent-scope load).  BLOCK: the four waves' maxima meet in LDS and
+// one thread issues the atomicMax (conv_x3.hip x3_range_out: same-address atomics execute one after the other at the memory side); the
+// call must then be reached by every wave of the block exactly once per kernel.  Otherwise one atomicMax per wave and call.
+// `seen` = the slot's value loaded BEFORE the epilogue's stores (conv_range_seen): a load at the end of the block kept its LDS and
+// registers allocated for a round trip to the memory side, ~2 us on blocks that live 10 - 20 us.
+__device__ __forceinline__ unsigned conv_range_seen(const unsigned* slot) {
+  return slot ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+template <bool BLOCK>
+__device__ __forceinline__ void conv_range_out(unsigned* slot, float m, unsigned seen) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) {
-    const unsigned b = __float_as_uint(m);
-    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  unsigned b = __float_as_uint(m);
+  if constexpr (BLOCK) {
+    __shared__ unsigned wave_max[4];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = b;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (threadIdx.x != 0) return;
+    const unsigned b01 = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1], b23 = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
+    b = b01 > b23 ? b01 : b23;
+  } else if ((threadIdx.x & 63) != 0) {
+    return;
   }
+  if (b > seen) atomicMax(slot, b);
 }
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -87,10 +103,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // Epilogue shared by the MFMA kernels: lane (fi, fg) holds, per 16x16 tile, 4 consecutive
 // couts (4*fg..4*fg+3) of pixel fi.
-template <int MT, int NT>
+template <int MT, int NT, bool RANGE_BLOCK = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int img, int oh0,
                                               int ow0, int n0, int wm, int wn, int fi, int fg) {
   float ym = 0.0f;
+  const unsigned yr_seen = conv_range_seen(a.yr);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int r = wm * MT * 16 + mi * 16 + fi;
@@ -143,7 +160,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
       }
     }
   }
-  if (a.yr) conv_range_out(a.yr, ym);
+  if (a.yr) conv_range_out<RANGE_BLOCK>(a.yr, ym, yr_seen);
 }
 
 // Row-contiguous epilogue for the LDS-DMA kernel (BN >= 32, every output channel stored): in the MFMA accumulator layout a
@@ -175,6 +192,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
   const float4 s4 = a.scale ? *reinterpret_cast<const float4*>(a.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 t4 = a.scale ? *reinterpret_cast<const float4*>(a.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   float ym = 0.0f;
+  const unsigned yr_seen = conv_range_seen(a.yr);
 #pragma unroll 4
   for (int e = tid; e < TOTAL; e += 256) {
     const int r = e / QR;
@@ -201,7 +219,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     *reinterpret_cast<float4*>(a.y + pix * a.y_cs + co) = v;
     if (a.yr) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v.x)), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
   }
-  if (a.yr) conv_range_out(a.yr, ym);
+  if (a.yr) conv_range_out<true>(a.yr, ym, yr_seen);
 }
 
 // FAST: (C1+C2) % 32 == 0 and the two sources split on a 32-channel boundary, so the tap,
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(256) void conv_rega_kernel(const ConvArgs a) {
         }
       }
     }
-    conv_epilogue<MT, NT>(a, acc, img, oh0, ow0, 0, wave, 0, fi, fg);
+    conv_epilogue<MT, NT, false>(a, acc, img, oh0, ow0, 0, wave, 0, fi, fg);       // (per tile of the loop: per-wave range atomics)
   }
 }
 

@@ -115,15 +115,22 @@ __device__ __forceinline__ void x3_split4(const f32x4 v, float xs, unsigned (&h)
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[p]) : "v"(t1), "s"(k2048));
   }
 }
-// max |y| of a wave -> the range slot: one no-return atomicMax per wave, and only when the wave's maximum exceeds what the slot already
-// holds (an agent-scope load: atomics execute at the memory side) -- after the first round of blocks almost no wave issues one
+// max |y| of a block -> the range slot: the waves' maxima meet in LDS (dead after the tap loop's last barrier) and ONE thread issues a
+// no-return atomicMax, and only when the block's maximum exceeds what the slot already holds.  Atomics execute at the memory side, one
+// after the other per address (measured ~4 ns each): one per WAVE cost the small layers of the U-Nets 15 - 35 us per launch, all of it
+// in the first round of blocks, which finish together and all still see the slot empty.
 // `seen` = the slot's value loaded at the START of the epilogue (the load's round trip to the memory side runs under the stores)
-__device__ __forceinline__ void x3_range_out(unsigned* slot, float m, int lane, unsigned seen) {
+__device__ __forceinline__ void x3_range_out(unsigned* slot, float m, int lane, int wave, unsigned seen, unsigned* lds) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if (lane == 0) {
-    const unsigned b = __float_as_uint(m);
+  if (lane == 0) lds[wave] = __float_as_uint(m);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (not __syncthreads(): that would also sit out the output stores)
+  if (threadIdx.x == 0) {
+    const unsigned b01 = lds[0] > lds[1] ? lds[0] : lds[1], b23 = lds[2] > lds[3] ? lds[2] : lds[3];
+    const unsigned b = b01 > b23 ? b01 : b23;                  // non-negative floats order like their bit patterns
+#ifndef SHDR_ABL_NO_RANGE_ATOMIC
     if (b > seen) atomicMax(slot, b);
+#endif
   }
 }
 
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     for (int j = 0; j < LRJ; ++j)
       if (tid + 256 * j < LRPIX * 8) *reinterpret_cast<f32x4*>(lrs + 4 * (tid + 256 * j)) = pr[j];
   };
-  float xs, ixs;                                               // input scale 2^T and its inverse
-  x3_range_scale(a.xr1, a.xr2, xs, ixs);
+  float xs = 1.0f, ixs = 1.0f;                                 // input scale 2^T and its inverse: set BEHIND the first patch / filter loads below (the
+                                                               // slot is a dependent scalar load: in front of them it delayed every block's first fetch)
   auto split_store = [&](int dst, const f32x4 v4) __attribute__((always_inline)) {            // one float4 -> 8 bytes in each fp16 image
     unsigned h[2], l[2];
     x3_split4(v4, xs, h, l);
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 
   load_patch(0);
   load_filt(0);
+  x3_range_scale(a.xr1, a.xr2, xs, ixs);
   if (UP) {
     park_lr();
     __syncthreads();
@@ -423,14 +431,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
           continue;
         }
         v[r] += bias_r[ni];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act1);
+        shdr::act_apply4<false>(v[r], a.act1);
         if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[r][e] = shdr::act_apply(v[r][e], a.act2);
+        shdr::act_apply4<false>(v[r], a.act2);
         if (a.y && oh + r < a.H && ow < a.W)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
+#ifndef SHDR_ABL_NO_YM
         if (a.yr && oh + r < a.H) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[r][0])), fabsf(v[r][1])), fabsf(v[r][2])), fabsf(v[r][3]));      // two v_max3_f32
+#endif
       }
       if (a.yp && a.final) {
         f32x4 m;
@@ -449,7 +457,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       }
     }
   }
-  if (a.yr && a.final) x3_range_out(a.yr, ow < a.W ? ym : 0.0f, lane, yr_seen);      // (a pooled output is bounded by the same maximum)
+#ifndef SHDR_ABL_NO_TAIL
+  if (a.yr && a.final) x3_range_out(a.yr, ow < a.W ? ym : 0.0f, lane, wave, yr_seen, reinterpret_cast<unsigned*>(xsm));      // (a pooled output is bounded by the same maximum)
+#endif
 }
 
 #undef patch_h
@@ -554,6 +564,7 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
   if (cv != d->Cout || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
   if (SHDR_ENV("SHDR_NO_X3")) return 0;
+  if (d->act1 == SHDR_ACT_TANH || d->act2 == SHDR_ACT_TANH) return 0;      // no wide layer of the networks has one: tanhf is not compiled in (act_apply4)
   if (d->stride == 1) {
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad_t == 1 && d->pad_l == 1;
     // 1 x 1 layers (the skip layers of hallucination_net.py:93-107 on tf.concat of two sources, the bottleneck convs of the ResNet

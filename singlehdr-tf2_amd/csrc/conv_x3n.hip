@@ -75,12 +75,19 @@ __device__ __forceinline__ void xn_split4(const f32x4 v, float xs, unsigned (&h)
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[p]) : "v"(t1), "s"(k2048));
   }
 }
-__device__ __forceinline__ void xn_range_out(unsigned* slot, float m, int lane) {
+// max |y| of a persistent block -> the range slot: one atomicMax per BLOCK (conv_x3.hip x3_range_out: the blocks all finish together,
+// same-address atomics execute one after the other at the memory side); the waves' maxima meet in four LDS words behind the images
+__device__ __forceinline__ void xn_range_out(unsigned* slot, float m, int lane, int wave, unsigned* lds) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if (lane == 0) {
-    const unsigned b = __float_as_uint(m);
+  if (lane == 0) lds[wave] = __float_as_uint(m);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (threadIdx.x == 0) {
+    const unsigned b01 = lds[0] > lds[1] ? lds[0] : lds[1], b23 = lds[2] > lds[3] ? lds[2] : lds[3];
+    const unsigned b = b01 > b23 ? b01 : b23;
+#ifndef SHDR_ABL_NO_RANGE_ATOMIC
     if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+#endif
   }
 }
 
@@ -99,10 +106,12 @@ struct NG {
   static constexpr int COUT = NT * 16;
   static constexpr int FILT_HALVES = NS * COUT * 32;           // one image
   static constexpr int FINSTR = 2 * NS * COUT / 16;            // filter DMA instructions, both images (16 rows of 64 bytes each)
-  static constexpr int LDS_BYTES = (2 * FILT_HALVES + 2 * PATCH_HALVES) * 2;
+  static constexpr int IMAGE_BYTES = (2 * FILT_HALVES + 2 * PATCH_HALVES) * 2;
+  static constexpr int LDS_BYTES = IMAGE_BYTES + 16;           // + the waves' output maxima (xn_range_out)
 };
 
-template <int KK, int CT, int NT, bool TWO>
+// TANH: the epilogue knows SHDR_ACT_TANH (instantiated for the 16-cout single-source layers only: shdr_conv2d_x3n_ok_f32)
+template <int KK, int CT, int NT, bool TWO, bool TANH>
 __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
   using G = NG<KK, CT, NT, TWO>;
   constexpr int MT = 4;                                        // wave w owns tile rows 4w .. 4w+3
@@ -151,8 +160,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       pch[j] = (ok && 4 * c4 < a.C1) ? 4 * c4 : -1;            // channels beyond the source's (3 -> 4, 9 -> 12 padded inputs) are zero
     }
   }
-  float xs, ixs;                                               // input scale 2^T and its inverse (conv_x3.hip "Range")
-  xn_range_scale(a.xr1, a.xr2, xs, ixs);
+  float xs = 1.0f, ixs = 1.0f;                                 // input scale 2^T and its inverse (conv_x3.hip "Range"): set behind the first patch loads
   f32x4 pr[G::PJ];
   // the 7x7 image layers (4 -> 16: four stores per tile and a long tap loop) measured 0.157 ms with compiler-scheduled loads against
   // 0.205 with the asm loads + counted wait that help every other shape: they keep the plain loads
@@ -235,7 +243,6 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
     const int row = ni * 16 + fi;
     b_rd[ni] = row * 32 + 8 * (fg ^ pswz(row));
   }
-  const float inv_s = a.hdr[1] * ixs;
 
   // Workgroup barriers of the tile loop order LDS traffic only: __syncthreads() also fences global memory (s_waitcnt vmcnt(0)), i.e.
   // every wave would sit out the write latency of the previous tile's output stores at the top of each tile (PMC on the 3x3 4 -> 64
@@ -251,6 +258,10 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
   float ym = 0.0f;                                             // max |y| over the values this lane stores (a.yr)
   int tile = blockIdx.x;
   if (tile < a.ntiles) load_patch(tile);
+#ifndef SHDR_ABL_NO_SCALE
+  xn_range_scale(a.xr1, a.xr2, xs, ixs);                     // behind the first patch loads: the slot's round trip hides under theirs
+#endif
+  const float inv_s = a.hdr[1] * ixs;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the filter (LDS-DMA) have landed
   int stores_since = -1;                                        // output store instructions this wave issued after its last patch loads (-1: unknown)
   for (; tile < a.ntiles; tile += gridDim.x) {
@@ -328,29 +339,39 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
         // y = act2(affine(act1(acc + bias)) + residual)
         if (a.cout_valid == G::COUT) {
           v += bias_r[ni];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act1);
+          shdr::act_apply4<TANH>(v, a.act1);
           if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + co) + *reinterpret_cast<const f32x4*>(a.shift + co);
           if (a.res) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += a.res[pix * a.res_cs + co + e];
           }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = shdr::act_apply(v[e], a.act2);
+          shdr::act_apply4<TANH>(v, a.act2);
           // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
           *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
+#ifndef SHDR_ABL_NO_YM
           if (a.yr) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[0])), fabsf(v[1])), fabsf(v[2])), fabsf(v[3]));
+#endif
           acc[mi][ni] = v;                                            // kept for the pooled output below
-        } else {
+        } else {                                                      // a zero-padded filter (e.g. 3 of 16 couts stored): guarded scalar accesses
+          if (co >= a.cout_valid) continue;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (a.bias && co + e < a.cout_valid) t[e] = a.bias[co + e];
+          v += t;
+          shdr::act_apply4<TANH>(v, a.act1);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (co + e < a.cout_valid) {
-              float t = shdr::act_apply(v[e] + (a.bias ? a.bias[co + e] : 0.f), a.act1);
-              if (a.scale) t = t * a.scale[co + e] + a.shift[co + e];
-              if (a.res) t += a.res[pix * a.res_cs + co + e];
-              t = shdr::act_apply(t, a.act2);
-              a.y[pix * a.cout_valid + co + e] = t;
-              if (a.yr) ym = fmaxf(ym, fabsf(t));
+              if (a.scale) v[e] = v[e] * a.scale[co + e] + a.shift[co + e];
+              if (a.res) v[e] += a.res[pix * a.res_cs + co + e];
+            }
+          shdr::act_apply4<TANH>(v, a.act2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.cout_valid) {
+              a.y[pix * a.cout_valid + co + e] = v[e];
+              if (a.yr) ym = fmaxf(ym, fabsf(v[e]));
             }
         }
       }
@@ -382,7 +403,9 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
       }
     }
   }
-  if (a.yr) xn_range_out(a.yr, ym, lane);                         // once per persistent block and wave (a pooled output has the same bound)
+#ifndef SHDR_ABL_NO_TAIL
+  if (a.yr) xn_range_out(a.yr, ym, lane, wave, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(nsm) + G::IMAGE_BYTES));                        // once per persistent block and wave (a pooled output has the same bound)
+#endif
 #undef filt_h
 #undef filt_l
 #undef patch_h
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(256) void x3n_pack_kernel(const float* __restrict__
   }
 }
 
-template <int KK, int CT, int NT, bool TWO>
+template <int KK, int CT, int NT, bool TWO, bool TANH = false>
 int launch_x3n(X3nArgs& a, hipStream_t st) {
   using G = NG<KK, CT, NT, TWO>;
   constexpr int lds = G::LDS_BYTES;
@@ -435,16 +458,16 @@ int launch_x3n(X3nArgs& a, hipStream_t st) {
     static bool attr_done[shdr::kMaxDevices] = {};
     static int occ[shdr::kMaxDevices] = {};
     if (!attr_done[dev_slot]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO, TANH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
       int nb = 0;
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO>), 256, lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_x3n_kernel<KK, CT, NT, TWO, TANH>), 256, lds);
       occ[dev_slot] = (e != hipSuccess || nb < 1) ? 1 : (nb > 4 ? 4 : nb);
       attr_done[dev_slot] = true;
     }
     long grid = 256L * occ[dev_slot];
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL((conv_x3n_kernel<KK, CT, NT, TWO>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_x3n_kernel<KK, CT, NT, TWO, TANH>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return shdr::check_launch("conv_x3n_kernel");
   }
 }
@@ -455,6 +478,13 @@ template <int KK, int NT>
 int dispatch_ct(X3nArgs& a, const shdr_conv2d_desc* d, hipStream_t st) {
   if (d->C2 > 0) return launch_x3n<KK, 32, NT, true>(a, st);
   const int ct = ct_of(d);
+  if constexpr (NT == 1) {                                   // the tanh heads of the U-Nets (16 couts, 3 stored): the only TANH instantiations
+    if (d->act1 == SHDR_ACT_TANH || d->act2 == SHDR_ACT_TANH) {
+      if (ct == 8) return launch_x3n<KK, 8, 1, false, true>(a, st);
+      if (ct == 16) return launch_x3n<KK, 16, 1, false, true>(a, st);
+      return launch_x3n<KK, 32, 1, false, true>(a, st);
+    }
+  }
   if (ct == 8) return launch_x3n<KK, 8, NT, false>(a, st);
   if (ct == 16) return launch_x3n<KK, 16, NT, false>(a, st);
   return launch_x3n<KK, 32, NT, false>(a, st);
@@ -473,6 +503,8 @@ extern "C" int shdr_conv2d_x3n_ok_f32(const shdr_conv2d_desc* d) {
   if (!(d->Cout == 16 || d->Cout == 32 || image64) || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv > d->Cout || (d->y_cstride != 0 && d->y_cstride != cv)) return 0;
+  // tanh is compiled into the 16-cout single-source kernels only (act_apply4: its code would evict the tile loop from the instruction cache)
+  if ((d->act1 == SHDR_ACT_TANH || d->act2 == SHDR_ACT_TANH) && !(d->Cout == 16 && d->C2 == 0)) return 0;
   const bool one = d->C2 == 0 && d->C1 % 4 == 0 && d->C1 >= 4 && d->C1 <= 32, two = d->C1 == 16 && d->C2 == 16;
   if (!(one || two) || SHDR_ENV("SHDR_NO_X3") || SHDR_ENV("SHDR_NO_X3N")) return 0;
   if ((long)d->N * d->H * d->W * 32 >= (1L << 31)) return 0;

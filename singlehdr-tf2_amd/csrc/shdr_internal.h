@@ -132,4 +132,30 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// The activation of four values at once: ONE uniform dispatch per vector instead of one per element, and tanhf -- an inlined libm
+// routine of ~45 instructions -- only in kernels instantiated with TANH.  The epilogues of the convolution kernels apply two
+// activations to 64 accumulators per lane: with act_apply() per element the epilogue alone was 40 - 70 KB of code (256 copies of
+// tanhf), more than the 64 KB instruction cache, and it sits inside the tile loop of the persistent kernels.
+template <bool TANH, class V4>
+__device__ __forceinline__ void act_apply4(V4& v, int act) {
+  switch (act) {
+    case SHDR_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+      break;
+    case SHDR_ACT_LRELU:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * 0.1f;
+      break;
+    case SHDR_ACT_TANH:
+      if constexpr (TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      break;
+    default:
+      break;
+  }
+}
+
 }  // namespace shdr

@@ -165,6 +165,8 @@ def test_planned_call_costs_what_the_fused_kernel_costs(lib):
                                                            ptr(slots), None, ctypes.c_void_p(slots.data_ptr() + 4), stream()))
     t_ranged = timeit(ranged_x3)
     assert torch.equal(y, y_measured) and float(slots[1]) == float(y.abs().max())
+    for _ in range(2):          # the chip is power-limited under this kernel and its clock drifts: alternate the two, keep the best of each
+        t_x3, t_ranged = min(t_x3, timeit(planned_x3)), min(t_ranged, timeit(ranged_x3))
     assert t_ranged <= 1.03 * t_x3 + 0.01, (t_ranged, t_x3)      # (the measuring pass it saves is 3 % of this layer; run-to-run noise is 2 %)
 
 
