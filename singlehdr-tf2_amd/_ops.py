@@ -140,7 +140,7 @@ class range_scope:
     SLOTS = 256
 
     def __enter__(self):
-        self._slab, self._n = None, 0
+        self._slabs = {}                   # (device, stream) -> [slab, slots taken]
         _RANGE_SCOPES.append(self)
         return self
 
@@ -149,10 +149,14 @@ class range_scope:
         return False
 
     def take(self, device):
-        if self._slab is None or self._n == self.SLOTS or self._slab.device != device:
-            self._slab, self._n = torch.zeros(self.SLOTS, device=device, dtype=torch.float32), 0
-        self._n += 1
-        return self._slab[self._n - 1:self._n]
+        # one slab per stream: its zero-fill is ordered in front of the kernels that write its slots by the stream itself (the backward
+        # pass of a multi-stream step takes slots on the stream of each node's forward op)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ent = self._slabs.get(key)
+        if ent is None or ent[1] == self.SLOTS:
+            ent = self._slabs[key] = [torch.zeros(self.SLOTS, device=device, dtype=torch.float32), 0]
+        ent[1] += 1
+        return ent[0][ent[1] - 1:ent[1]]
 
 
 RANGE_MISSES = collections.Counter()      # split-operand layers whose input arrived without a range (diagnostic: each costs one pass over x)
@@ -488,6 +492,8 @@ def conv2d_dgrad(dz, w, x_shape, c1, c2, which, stride=1, x2_scale=1.0):
     # range slots (a chain conv <- activation <- conv of a backward pass never measures: |act' dz| <= |dz|, _carry_range)
     zr = _range_of(dz_in)
     xr = _new_slot(dz.device) if int(lib.shdr_conv2d_dgrad_tracks_range_f32(ctypes.byref(d), int(which))) else None
+    if zr is None and xr is not None:
+        RANGE_MISSES[("dgrad", tuple(dz.shape), tuple(w.shape))] += 1
     _lib.check(lib.shdr_conv2d_dgrad_ranged_f32(ctypes.byref(d), int(which), _ptr(dz), _ptr(w), _ptr(dx), _ptr(ws), _ptr(zr), _ptr(xr), _stream()),
                "shdr_conv2d_dgrad_ranged_f32")
     if xr is not None:
@@ -778,6 +784,7 @@ def _split_planes(lib, t, slot):
     """(high plane, low plane, range slot) of an fp32 tensor for the split-operand weight gradient; the range is measured when the
     tensor carries no slot (output gradients never do)"""
     if slot is None:
+        RANGE_MISSES[("wgrad operand", tuple(t.shape))] += 1
         slot = _new_slot(t.device)
         _lib.check(lib.shdr_absmax_f32(_ptr(t), t.numel(), _ptr(slot), _stream()), "shdr_absmax_f32")
     hi = torch.empty(t.shape, device=t.device, dtype=torch.float16)

@@ -335,9 +335,11 @@ class JointTrainStep:
         out = self.losses(ds, invcrf)
         self._hal._decoder_grads_done = None
         if dp and self.bucketed:
-            self._bucketed_backward(out)
+            with K.range_scope():                         # the backward pass's range slots (one zeroed slab per stream)
+                self._bucketed_backward(out)
         else:
-            out["objective"].backward()                   # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
+            with K.range_scope():
+                out["objective"].backward()               # == total_loss.sum() on one GPU: the sum over the [b,1,b,1] tensor
             self._join_streams()
             if dp:
                 import torch.distributed as dist
@@ -417,8 +419,8 @@ class TrainStep:
         self._objective = None
         with K.range_scope():
             loss, outputs = self.forward(ds)
-        # tape.gradient of a non-scalar loss = gradient of its sum (for `lin` the sum over the broadcast [b,1,b,1] tensor)
-        (loss.sum() if self._objective is None else self._objective).backward()
+            # tape.gradient of a non-scalar loss = gradient of its sum (for `lin` the sum over the broadcast [b,1,b,1] tensor)
+            (loss.sum() if self._objective is None else self._objective).backward()
         if self.pg is not None and self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)

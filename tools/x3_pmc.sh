@@ -10,7 +10,9 @@ TAG="${4:-${HW}_${CIN}_${COUT}}"
 O="$R/gpurun_out/x3_pmc/$TAG"
 mkdir -p "$O"
 i=0
-for SET in "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE" "SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"; do
+DEFAULT_SETS="GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES;SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS;SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT;SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE;SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"
+IFS=';' read -ra SETS <<< "${X3_PMC_SETS:-$DEFAULT_SETS}"       # X3_PMC_SETS="A B;C D": other counter passes
+for SET in "${SETS[@]}"; do
   i=$((i+1))
   # shellcheck disable=SC2086
   rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$O/p$i" -- python3 "$R/tools/x3_one.py" "$HW" "$CIN" "$COUT" > "$O/p$i.log" 2>&1 || echo "pass $i failed"
