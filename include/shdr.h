@@ -292,6 +292,9 @@ int shdr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int 
 /* tf.clip_by_value gradient: passes where lo <= x <= hi. */
 int shdr_clip_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, float lo, float hi, void* stream);
 int shdr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* the same; y_range (or NULL) = range slot that receives max |y|: the sums of a backward pass (a forked tensor's gradients, a residual
+ * join) feed split-operand input / weight gradients, which then need not measure them */
+int shdr_add_ranged_f32(const float* a, const float* b, float* y, int64_t n, float* y_range, void* stream);
 /* input gradients of the pooling / resize ops; N,H,W,C describe the op's INPUT x. */
 int shdr_avgpool2_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 int shdr_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
@@ -299,6 +302,8 @@ int shdr_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int N, int
  * earlier element of the window does). */
 int shdr_maxpool3s2_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* the same; dx_range (or NULL) = range slot that receives max |dx| (shdr_add_ranged_f32) */
+int shdr_resize2x_bwd_ranged_f32(const float* dy, float* dx, int N, int H, int W, int C, float* dx_range, void* stream);
 int shdr_gap_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream);
 /* dx[n,2i,2j,:] = dy[n,i,j,:], zero elsewhere (input gradient of a 1x1 stride-2 conv). */
 int shdr_upsample_zero2_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
@@ -319,6 +324,10 @@ int shdr_bn_train_apply_ranged_f32(const float* x, const float* mean, const floa
 int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean,
                     const float* var, const float* gamma, double* ws, float* dgamma, float* dbeta,
                     float* dx, int64_t npix, int C, float eps, void* stream);
+/* the same; dx_range (or NULL) = range slot that receives max |dx| */
+int shdr_bn_bwd_ranged_f32(const float* dy, const float* x, const float* y_relu, const float* mean,
+                           const float* var, const float* gamma, double* ws, float* dgamma, float* dbeta,
+                           float* dx, int64_t npix, int C, float eps, float* dx_range, void* stream);
 int shdr_invcrf_decode_bwd_f32(const float* dinv, const float* feat, const float* wfc,
                                const float* table, float* dfeat, float* dwfc, float* dbfc, int B,
                                int F, int K, void* stream);

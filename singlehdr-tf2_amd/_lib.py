@@ -110,16 +110,19 @@ SIGNATURES = {
     "shdr_act_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "shdr_clip_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_ptr]),
     "shdr_add_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "shdr_add_ranged_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "shdr_avgpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_maxpool2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_maxpool3s2_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_resize2x_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "shdr_resize2x_bwd_ranged_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "shdr_gap_bwd_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "shdr_upsample_zero2_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "shdr_bn_stats_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_ptr]),
     "shdr_bn_train_apply_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr]),
     "shdr_bn_train_apply_ranged_f32": (c_int, [c_ptr] * 6 + [c_i64, c_int, c_f32, c_int, c_ptr, c_ptr]),
     "shdr_bn_bwd_f32": (c_int, [c_ptr] * 10 + [c_i64, c_int, c_f32, c_ptr]),
+    "shdr_bn_bwd_ranged_f32": (c_int, [c_ptr] * 10 + [c_i64, c_int, c_f32, c_ptr, c_ptr]),
     "shdr_invcrf_decode_bwd_f32": (c_int, [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr]),
     "shdr_increase_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "shdr_apply_rf_bwd_f32": (c_int, [c_ptr] * 5 + [c_int, c_i64, c_int, c_ptr]),

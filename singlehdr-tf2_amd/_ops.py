@@ -899,19 +899,19 @@ def act_bwd_bias(dy, y, act, out=None):
     c = dy.shape[-1]
     q = c // 4
     if c % 4 or q > 256 or q & (q - 1):
-        dz = act_bwd(dy, y, act) if act != ACT_NONE else dy
+        dz = act_bwd(dy_in, y, act) if act != ACT_NONE else dy_in
         return dz, bias_grad(dz, out)
     lib = _lib.load()
     db = out if out is not None else torch.zeros(c, device=dy.device, dtype=torch.float32)
     if act == ACT_NONE:
-        dz, yp, zp = dy, None, None
+        dz, yp, zp = dy_in, None, None  # (the caller's tensor object: it carries the range slot)
     else:
         y = _chk(_d(y), "y")
         dz = torch.empty_like(dy)
         yp, zp = _ptr(y), _ptr(dz)
     _lib.check(lib.shdr_act_bwd_bias_f32(_ptr(dy), yp, zp, _ptr(db), _ptr(_bias_ws(c, dy.device)), dy.numel() // c, c, act, _stream()),
                "shdr_act_bwd_bias_f32")
-    if dz is not dy:
+    if dz is not dy_in:
         _carry_range(dz, dy_in)         # |act'(y)| <= 1
     return dz, db
 
@@ -956,8 +956,9 @@ def add(a, b, relu=False):
     if a.shape != b.shape:
         raise ValueError("add: shape mismatch")
     y = torch.empty_like(a)
-    _lib.check(lib.shdr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "shdr_add_f32")
-    return y
+    yr = _new_slot(a.device)            # max |a + b| out of the same pass (a gradient sum usually feeds a split-operand dgrad / wgrad)
+    _lib.check(lib.shdr_add_ranged_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _ptr(yr), _stream()), "shdr_add_ranged_f32")
+    return _set_range(y, yr)
 
 
 def mark(x, callback):
@@ -1009,11 +1010,11 @@ def _bwd_nhwc(fn_name, x_shape, *tensors):
 
 
 def avgpool2_bwd(dy, x_shape):
-    return _bwd_nhwc("shdr_avgpool2_bwd_f32", x_shape, dy)
+    return _carry_range(_bwd_nhwc("shdr_avgpool2_bwd_f32", x_shape, dy), dy)          # dy / 4
 
 
 def maxpool2_bwd(x, dy):
-    return _bwd_nhwc("shdr_maxpool2_bwd_f32", x.shape, x, dy)
+    return _carry_range(_bwd_nhwc("shdr_maxpool2_bwd_f32", x.shape, x, dy), dy)       # dy or 0 (disjoint windows)
 
 
 def maxpool3s2_bwd(x, y, dy):
@@ -1022,11 +1023,19 @@ def maxpool3s2_bwd(x, y, dy):
 
 
 def resize2x_bwd(dy, x_shape):
-    return _bwd_nhwc("shdr_resize2x_bwd_f32", x_shape, dy)
+    if _is_h(dy):
+        return _bwd_nhwc("shdr_resize2x_bwd_f32", x_shape, dy)
+    lib = _lib.load()
+    dy = _chk(_d(dy), "dy")
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    xr = _new_slot(dy.device)           # max |dx| out of the same pass (the consumer is the input gradient of the conv in front)
+    _lib.check(lib.shdr_resize2x_bwd_ranged_f32(_ptr(dy), _ptr(dx), n, h, w, c, _ptr(xr), _stream()), "shdr_resize2x_bwd_ranged_f32")
+    return _set_range(dx, xr)
 
 
 def upsample_zero2(dy, x_shape):
-    return _bwd_nhwc("shdr_upsample_zero2_f32", x_shape, dy)
+    return _carry_range(_bwd_nhwc("shdr_upsample_zero2_f32", x_shape, dy), dy)         # dy or 0
 
 
 def gap_bwd(dy, x_shape, dtype=torch.float32):
@@ -1088,10 +1097,15 @@ def bn_bwd(dy, x, y_relu, mean, var, gamma, eps, dgamma_out=None, dbeta_out=None
     dbeta = dbeta_out if dbeta_out is not None else torch.zeros(c, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     ws = _bn_ws(c, x.device)
-    fn = "shdr_bn_bwd_f16" if h else "shdr_bn_bwd_f32"
-    _lib.check(getattr(lib, fn)(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
-                                _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _stream()), fn)
-    return dx, dgamma, dbeta
+    if h:
+        _lib.check(lib.shdr_bn_bwd_f16(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _stream()), "shdr_bn_bwd_f16")
+        return dx, dgamma, dbeta
+    xr = _new_slot(x.device)            # max |dx| out of the apply pass (the consumer is the input / weight gradient of the conv in front)
+    _lib.check(lib.shdr_bn_bwd_ranged_f32(_ptr(dy), _ptr(x), _ptr(_d(y_relu)), _ptr(mean), _ptr(var), _ptr(_d(gamma)), _ptr(ws),
+                                          _ptr(dgamma), _ptr(dbeta), _ptr(dx), x.numel() // c, c, float(eps), _ptr(xr), _stream()),
+               "shdr_bn_bwd_ranged_f32")
+    return _set_range(dx, xr), dgamma, dbeta
 
 
 def invcrf_decode_bwd(dinv, feat, wfc, table):

@@ -127,9 +127,17 @@ __global__ __launch_bounds__(256) void clip_bwd_kernel(const float* __restrict__
   }
 }
 
+// yr: range slot of y or null (the sums of a backward pass -- forked tensors, residual joins -- feed split-operand input / weight
+// gradients: tracking max |y| here saves their measuring pass)
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                  float* __restrict__ y, long n) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i] + b[i];
+                                                  float* __restrict__ y, long n, unsigned* __restrict__ yr) {
+  float ym = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = a[i] + b[i];
+    y[i] = v;
+    ym = fmaxf(ym, fabsf(v));
+  }
+  if (yr) shdr::range_out_block256(yr, ym);
 }
 
 // (e < 2^32 for every tensor below 64 GB: three 32-bit divisions -- about 25 instructions each -- instead of three emulated
@@ -250,9 +258,10 @@ __device__ __forceinline__ void resize_taps(int m, int n_in, int* idx, float* wt
   *cnt = k;
 }
 __global__ __launch_bounds__(256) void resize2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                           int N, int H, int W, int C) {
+                                                           int N, int H, int W, int C, unsigned* __restrict__ xr) {
   const int Q = C >> 2, Ho = 2 * H, Wo = 2 * W;
   const long total = (long)N * H * W * Q;
+  float dm = 0.f;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     SHDR_DECODE_QUAD(e, Q, W, H, q, w, h, n)
     int yi[4], xi[4], ny, nx;
@@ -267,7 +276,9 @@ __global__ __launch_bounds__(256) void resize2x_bwd_kernel(const float* __restri
         s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
       }
     st4(dx + e * 4, s);
+    dm = fmaxf(fmaxf(fmaxf(fmaxf(dm, fabsf(s.x)), fabsf(s.y)), fabsf(s.z)), fabsf(s.w));
   }
+  if (xr) shdr::range_out_block256(xr, dm);                    // (a sum of up to nine weighted taps: not bounded by max |dy|)
 }
 
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
@@ -457,17 +468,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float* __rest
     y[i] = v;
     ym = fmaxf(ym, fabsf(v));
   }
-  if (yr) {                                                    // range slot of y (conv_x3.hip "Range"): the consumer is usually a split-operand conv
-    __shared__ float part[4];                                  // one filtered atomicMax per BLOCK (a grid of 2048 blocks ends on one address)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ym = fmaxf(ym, __shfl_xor(ym, off, 64));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ym;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned b = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
-      if (b > __hip_atomic_load(yr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(yr, b);
-    }
-  }
+  if (yr) shdr::range_out_block256(yr, ym);                     // range slot of y: the consumer is usually a split-operand conv
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, const float* __restrict__ var,
@@ -483,7 +484,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ var, const float* __restrict__ gamma,
                                                            const double* __restrict__ ws, float* __restrict__ dx,
-                                                           long total, long npix, int C, float eps) {
+                                                           long total, long npix, int C, float eps, unsigned* __restrict__ xr) {
+  float dm = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     float g = dy[i];
@@ -492,8 +494,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float xh = (x[i] - mean[c]) * invstd;
     const float m1 = (float)(ws[c] / (double)npix);
     const float m2 = (float)(ws[C + c] / (double)npix) * invstd;   // mean(dy' * xhat)
-    dx[i] = gamma[c] * invstd * (g - m1 - xh * m2);
+    const float o = gamma[c] * invstd * (g - m1 - xh * m2);
+    dx[i] = o;
+    dm = fmaxf(dm, fabsf(o));
   }
+  if (xr) shdr::range_out_block256(xr, dm);
 }
 
 // float4 form (C / 4 a power of two, grid * 256 a multiple of it): a thread's channel quad is fixed over its grid-stride
@@ -502,8 +507,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ var, const float* __restrict__ gamma,
                                                             const double* __restrict__ ws, float* __restrict__ dx,
-                                                            long nquads, long npix, int C, float eps) {
+                                                            long nquads, long npix, int C, float eps, unsigned* __restrict__ xr) {
   const int Q = C >> 2;
+  float dm = 0.f;
   const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % Q);
   float invstd[4], mu[4], m1[4], m2[4], ga[4];
 #pragma unroll
@@ -534,7 +540,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       o[e] = ga[e] * (g[e] - m1[e] - xh * m2[e]);
     }
     *reinterpret_cast<float4*>(dx + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+    dm = fmaxf(fmaxf(fmaxf(fmaxf(dm, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
   }
+  if (xr) shdr::range_out_block256(xr, dm);
 }
 
 // ---- inverse-CRF head backward --------------------------------------------------------------------
@@ -869,11 +877,14 @@ extern "C" int shdr_clip_bwd_f32(const float* dy, const float* x, float* dx, int
   hipLaunchKernelGGL(clip_bwd_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, S(stream), dy, x, dx, (long)n, lo, hi);
   return shdr::check_launch("clip_bwd");
 }
-extern "C" int shdr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
+extern "C" int shdr_add_ranged_f32(const float* a, const float* b, float* y, int64_t n, float* y_range, void* stream) {
   SHDR_REQUIRE(a && b && y, SHDR_E_NULL, "add: null pointer");
   SHDR_REQUIRE(n > 0, SHDR_E_SHAPE, "add: n must be positive");
-  hipLaunchKernelGGL(add_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, S(stream), a, b, y, (long)n);
+  hipLaunchKernelGGL(add_kernel, dim3(shdr::stream_grid(n)), dim3(256), 0, S(stream), a, b, y, (long)n, reinterpret_cast<unsigned*>(y_range));
   return shdr::check_launch("add");
+}
+extern "C" int shdr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  return shdr_add_ranged_f32(a, b, y, n, nullptr, stream);
 }
 extern "C" int shdr_avgpool2_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
   if (int rc = nhwc4("avgpool2_bwd", dy, dx, N, H, W, C)) return rc;
@@ -901,11 +912,14 @@ extern "C" int shdr_maxpool3s2_bwd_f32(const float* x, const float* y, const flo
                      x, y, dy, dx, N, H, W, C, Ho, Wo, pt, pl);
   return shdr::check_launch("maxpool3s2_bwd");
 }
-extern "C" int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int shdr_resize2x_bwd_ranged_f32(const float* dy, float* dx, int N, int H, int W, int C, float* dx_range, void* stream) {
   if (int rc = nhwc4("resize2x_bwd", dy, dx, N, H, W, C)) return rc;
   hipLaunchKernelGGL(resize2x_bwd_kernel, dim3(shdr::stream_grid((long)N * H * W * (C / 4))), dim3(256), 0, S(stream),
-                     dy, dx, N, H, W, C);
+                     dy, dx, N, H, W, C, reinterpret_cast<unsigned*>(dx_range));
   return shdr::check_launch("resize2x_bwd");
+}
+extern "C" int shdr_resize2x_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  return shdr_resize2x_bwd_ranged_f32(dy, dx, N, H, W, C, nullptr, stream);
 }
 extern "C" int shdr_gap_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream) {
   if (int rc = nhwc4("gap_bwd", dy, dx, N, HW, 1, C)) return rc;
@@ -943,9 +957,9 @@ extern "C" int shdr_bn_train_apply_f32(const float* x, const float* mean, const 
                                        const float* beta, float* y, int64_t npix, int C, float eps, int relu, void* stream) {
   return shdr_bn_train_apply_ranged_f32(x, mean, var, gamma, beta, y, npix, C, eps, relu, nullptr, stream);
 }
-extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean, const float* var,
-                               const float* gamma, double* ws, float* dgamma, float* dbeta, float* dx, int64_t npix,
-                               int C, float eps, void* stream) {
+extern "C" int shdr_bn_bwd_ranged_f32(const float* dy, const float* x, const float* y_relu, const float* mean, const float* var,
+                                      const float* gamma, double* ws, float* dgamma, float* dbeta, float* dx, int64_t npix,
+                                      int C, float eps, float* dx_range, void* stream) {
   SHDR_REQUIRE(dy && x && mean && var && gamma && ws && dgamma && dbeta && dx, SHDR_E_NULL, "bn_bwd: null pointer");
   SHDR_REQUIRE(npix > 0 && C > 0, SHDR_E_SHAPE, "bn_bwd: bad shape");
   hipStream_t st = S(stream);
@@ -958,12 +972,17 @@ extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_r
     const long unit = Q > 256 ? Q / 256 : 1;              // grid * 256 must be a multiple of Q
     grid = (grid + unit - 1) / unit * unit;
     hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)grid), dim3(256), 0, st, dy, x, y_relu, mean, var, gamma, ws, dx,
-                       (long)npix * Q, (long)npix, C, eps);
+                       (long)npix * Q, (long)npix, C, eps, reinterpret_cast<unsigned*>(dx_range));
   } else {
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(shdr::stream_grid(npix * C)), dim3(256), 0, st, dy, x, y_relu, mean, var,
-                       gamma, ws, dx, (long)npix * C, (long)npix, C, eps);
+                       gamma, ws, dx, (long)npix * C, (long)npix, C, eps, reinterpret_cast<unsigned*>(dx_range));
   }
   return shdr::check_launch("bn_bwd");
+}
+extern "C" int shdr_bn_bwd_f32(const float* dy, const float* x, const float* y_relu, const float* mean, const float* var,
+                               const float* gamma, double* ws, float* dgamma, float* dbeta, float* dx, int64_t npix,
+                               int C, float eps, void* stream) {
+  return shdr_bn_bwd_ranged_f32(dy, x, y_relu, mean, var, gamma, ws, dgamma, dbeta, dx, npix, C, eps, nullptr, stream);
 }
 
 extern "C" int shdr_invcrf_decode_bwd_f32(const float* dinv, const float* feat, const float* wfc, const float* table,

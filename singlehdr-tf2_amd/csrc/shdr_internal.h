@@ -132,6 +132,21 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// max |y| of a 256-thread block -> a range slot (conv_x3.hip "Range"): the waves' maxima meet in LDS and ONE thread issues the atomicMax,
+// only when the block's maximum exceeds what the slot already holds (same-address atomics execute one after the other at the memory
+// side).  Every thread of the block must call it.
+__device__ __forceinline__ void range_out_block256(unsigned* slot, float m) {
+  __shared__ float range_part[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) range_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned b = __float_as_uint(fmaxf(fmaxf(range_part[0], range_part[1]), fmaxf(range_part[2], range_part[3])));
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
+}
+
 // The activation of four values at once: ONE uniform dispatch per vector instead of one per element, and tanhf -- an inlined libm
 // routine of ~45 instructions -- only in kernels instantiated with TANH.  The epilogues of the convolution kernels apply two
 // activations to 64 accumulators per lane: with act_apply() per element the epilogue alone was 40 - 70 KB of code (256 copies of

@@ -507,6 +507,33 @@ def test_split_operand_range_slots_travel_with_the_tensors(shdr, monkeypatch):
         assert bool(torch.isfinite(y2).all()) and float((plain - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
 
 
+def test_backward_elementwise_kernels_track_their_output_range(shdr):
+    """the sums / BatchNorm and resize input gradients of a backward pass write max |out| into a range slot in the same pass
+    (shdr_add_ranged_f32, shdr_bn_bwd_ranged_f32, shdr_resize2x_bwd_ranged_f32); pooling gradients bounded by dy carry dy's slot"""
+    K = shdr._ops
+    rng = np.random.default_rng(11)
+    with torch.no_grad(), K.range_scope():
+        a, b = dev(f32(rng.normal(size=(2, 16, 16, 32)) * 1e-6)), dev(f32(rng.normal(size=(2, 16, 16, 32)) * 1e-6))
+        s = K.add(a, b)
+        assert torch.equal(s, a + b) and float(s._shdr_range) == float(s.abs().max())
+        x = dev(f32(rng.normal(size=(2, 16, 16, 32))))
+        mean, var = K.bn_stats(x)
+        gamma, beta = dev(f32(rng.normal(size=32))), dev(f32(rng.normal(size=32)))
+        y = K.bn_train_apply(x, mean, var, gamma, beta, 1e-3, True)
+        dx, _, _ = K.bn_bwd(s, x, y, mean, var, gamma, 1e-3)
+        assert float(dx._shdr_range) == float(dx.abs().max()) > 0.0
+        dx1, _, _ = K.bn_bwd(s[..., :3].contiguous(), x[..., :3].contiguous(), None, mean[:3].contiguous(), var[:3].contiguous(),
+                             gamma[:3].contiguous(), 1e-3)            # the scalar kernel (C % 4 != 0)
+        assert float(dx1._shdr_range) == float(dx1.abs().max()) > 0.0
+        big = dev(f32(rng.normal(size=(2, 32, 32, 32)) * 3e4))
+        r = K.resize2x_bwd(big, (2, 16, 16, 32))
+        assert float(r._shdr_range) == float(r.abs().max()) > float(big.abs().max())      # up to nine weighted taps add up
+        K.absmax_slot(big)
+        for g in (K.avgpool2_bwd(big, (2, 64, 64, 32)), K.maxpool2_bwd(dev(f32(rng.normal(size=(2, 64, 64, 32)))), big),
+                  K.upsample_zero2(big, (2, 64, 64, 32))):
+            assert g._shdr_range is big._shdr_range and float(g.abs().max()) <= float(big._shdr_range)
+
+
 WGRAD_X3_CASES = [("3x3_128_128", 2, 32, 32, 128, 0, 128, 3, 1), ("3x3_256_128_ragged", 1, 21, 37, 256, 0, 128, 3, 1),
                   ("3x3_two_sources_scaled", 2, 16, 24, 128, 128, 128, 3, 1), ("3x3_128_192", 1, 24, 24, 128, 0, 192, 3, 1),
                   ("3x3_stride2_256_128", 2, 32, 32, 256, 0, 128, 3, 2)]
