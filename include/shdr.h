@@ -172,6 +172,18 @@ int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, const float* 
                                         const float* bias, const float* scale, const float* shift, const float* residual, float* y,
                                         float* y_pool, void* workspace, const float* x1_range, const float* x2_range, float* y_range,
                                         void* stream);
+/* The planned forward call with a PROJECTED output: y_proj[n,h,w,j] = sum_c proj[j][c] * y[n,h,w,c] (proj: [3][Cout] floats, y_proj:
+ * [N,Ho,Wo,3]), formed in the epilogue that holds y in registers; y and y_pool are written only when given (either may be NULL).
+ * Replaces the pair "3x3 conv, then a 1x1 conv to 3 channels" where the 1x1 map is linear in the conv's output: the tail of the
+ * Hallucination-Net (hallucination_net.py:179-185: skip layer s1 on concat[u1, d1 / 255], then conv2 -- two linear maps in a row)
+ * needs only such a projection of u1 and of d1, whose full-resolution 64-channel tensors are then never written nor read back.
+ * shdr_conv2d_projected_ok_f32: 1 if the layer's planned kernel can do it (the split-operand plan, 64 output channels, stride 1);
+ * the call refuses other layers with SHDR_E_SHAPE (run the two convolutions then). */
+int shdr_conv2d_projected_ok_f32(const shdr_conv2d_desc* d);
+int shdr_conv2d_fwd_prepared_projected_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                           const float* bias, const float* scale, const float* shift, const float* proj, float* y_proj,
+                                           float* y, float* y_pool, void* workspace, const float* x1_range, const float* x2_range,
+                                           float* y_range, void* stream);
 
 /*
  * Convolution backward (GradientTape.gradient through Conv2D: joint_training.py:185,
@@ -447,6 +459,10 @@ int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const flo
 int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                   const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
                                   const float* x2_range, float* y_range, void* stream);
+/* the same launch with a projected output (see shdr_conv2d_fwd_prepared_projected_f32); proj [3][64], Cout = 64 */
+int shdr_conv2d_fwd_x3_projected_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                     const float* scale, const float* shift, const float* proj, float* y_proj, float* y, float* y_pool,
+                                     const float* x1_range, const float* x2_range, float* y_range, void* stream);
 /* range slot of a tensor: *range = max(*range, max |x|) (bit pattern of a non-negative float, atomicMax; the caller zeroes the slot) */
 int shdr_absmax_f32(const float* x, int64_t n, float* range, void* stream);
 

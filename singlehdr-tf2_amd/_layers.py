@@ -89,7 +89,7 @@ class Layer:
 
     def _drop_derived(self):
         """forget per-version derived tensors kept on the layers themselves (padded / composed filters)"""
-        for attr in ("_padded", "_tail"):
+        for attr in ("_padded", "_tail", "_tail_proj"):
             if getattr(self, attr, None) is not None:
                 object.__setattr__(self, attr, None)
         for _, child in self._children:
@@ -156,7 +156,7 @@ class Conv2D(Layer):
 
     def call_up2(self, x, **kw):
         """this layer applied to tf.image.resize(x, 2x, BILINEAR): one fused kernel where the library's plan allows it"""
-        return K.conv2d_up2(x, self.kernel, self.bias, **kw)
+        return K.conv2d_up2(x, self.kernel, self.bias, **kw)          # (kw may carry proj=: None comes back when it cannot be fused)
 
 
 class BatchNormalization(Layer):

@@ -159,6 +159,7 @@ class range_scope:
         return ent[0][ent[1] - 1:ent[1]]
 
 
+PROJECTED_LAUNCHES = [0]                  # convolutions that wrote a projected output from their epilogue (diagnostic / tests)
 RANGE_MISSES = collections.Counter()      # split-operand layers whose input arrived without a range (diagnostic: each costs one pass over x)
 
 
@@ -255,24 +256,30 @@ def conv2d(x, w, bias=None, stride=1, x2=None, x2_scale=1.0, act1=ACT_NONE, scal
                        w_batch_stride, None)
 
 
-def conv2d_up2(x, w, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE):
+def conv2d_up2(x, w, bias=None, act1=ACT_NONE, scale=None, shift=None, act2=ACT_NONE, proj=None):
     """Conv2D(SAME, stride 1)(tf.image.resize(x, 2x, BILINEAR)) with the conv2d epilogue -- the `up` blocks of
     hallucination_net.py:86-88 and dequantization_net.py:25-27.  Without a gradient tape the library fuses the resize into the
     convolution where the plan allows it (desc.prologue, csrc/conv_plan.hip); under a tape, and in the reduced-precision operand
-    modes, it is the two recorded ops."""
+    modes, it is the two recorded ops.
+    proj [3, Cout]: the PROJECTED output sum_c proj[j, c] y[..., c] instead of y (include/shdr.h:
+    shdr_conv2d_fwd_prepared_projected_f32), or None when the planned kernel of the layer cannot form it."""
     algo = _AUTO_ALGO[PRECISION]
     if _is_h(x) or algo != ALGO_AUTO or not WINOGRAD or _needs_grad(x, w, bias, scale, shift):
+        if proj is not None:
+            return None
         return conv2d(resize2x(x), w, bias, act1=act1, scale=scale, shift=shift, act2=act2)
     return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, scale, shift, None, act2, algo, None, None, None, None, 0, None,
-                       prologue=PROLOGUE_BILINEAR2X)
+                       prologue=PROLOGUE_BILINEAR2X, proj=proj)
 
 
 def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, act2, algo, out, cout_valid, pad, out_hw,
-                w_batch_stride, pool, prologue=0):
+                w_batch_stride, pool, prologue=0, proj=None):
     """One convolution through the C ABI.  The kernel family (one-kernel Winograd, three-kernel Winograd, register-A / LDS-DMA
     implicit GEMM, direct) is chosen BELOW the ABI (shdr_conv2d_plan_f32, csrc/conv_plan.hip); this wrapper only checks shapes,
     caches the prepared filter of persistent variables per version and provides memory.  pool: None, True (also return
-    MaxPool2D(2)(y)), "only" (the pooled tensor alone) or "avg" (also return AveragePooling2D(2)(y))."""
+    MaxPool2D(2)(y)), "only" (the pooled tensor alone) or "avg" (also return AveragePooling2D(2)(y)).
+    proj [3, Cout]: return the PROJECTED output [N, Ho, Wo, 3] (sum_c proj[j, c] y[..., c]) instead of y -- (y_proj, pooled) with a
+    pool -- or None when the layer's planned kernel cannot form it (conv2d_projected falls back to two convolutions)."""
     lib = _lib.load()
     x_in, x2_in = x, x2                # the tensors as handed over: they carry the range slots (a detached copy does not)
     x = _chk(_d(x), "x")
@@ -316,7 +323,13 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
                              % (tuple(residual.shape), n, ho, wo, cout))
         res_cs = residual.shape[3]
     d.res_cstride = res_cs
-    if out is None:
+    if proj is not None:
+        if algo != ALGO_AUTO or not WINOGRAD or residual is not None or not int(lib.shdr_conv2d_projected_ok_f32(ctypes.byref(d))):
+            return None
+        proj = _chk(_d(proj), "proj")
+        if tuple(proj.shape) != (3, cout):
+            raise ValueError("conv2d: proj must be [3, %d]" % cout)
+    elif out is None:
         out = None if pool == "only" else torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
     else:
         _chk(out, "out")
@@ -355,6 +368,16 @@ def _conv2d_raw(x, w, bias, stride, x2, x2_scale, act1, scale, shift, residual, 
             out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
     # the output's range slot: written by the epilogue of the split-operand and of the exact-fp32 MFMA / direct kernels (no extra pass)
     yr = _new_slot(x.device) if (split or (plan in (0, 1) and prologue == PROLOGUE_NONE and out is not None)) else None
+    if proj is not None:
+        yj = torch.empty((n, ho, wo, 3), device=x.device, dtype=torch.float32)
+        rc = lib.shdr_conv2d_fwd_prepared_projected_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
+                                                        _ptr(_d(shift)), _ptr(proj), _ptr(yj), None, _ptr(yp), _ptr(ws), _ptr(xr1),
+                                                        _ptr(xr2), _ptr(yr), _stream())
+        _lib.check(rc, "shdr_conv2d_fwd_prepared_projected_f32")
+        PROJECTED_LAUNCHES[0] += 1
+        if yp is not None:
+            _set_range(yp, yr)             # (the pooled copy of y is bounded by max |y|)
+        return (yj, yp) if pool else yj
     rc = lib.shdr_conv2d_fwd_prepared_ranged_f32(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(prepared), _ptr(_d(bias)), _ptr(_d(scale)),
                                                  _ptr(_d(shift)), _ptr(residual), _ptr(out), _ptr(yp), _ptr(ws), _ptr(xr1), _ptr(xr2),
                                                  _ptr(yr), _stream())
@@ -1537,11 +1560,18 @@ def _packed_filter(w):
     return _filter_cache_put(w, "_shdr_wino", "u", winograd_filter_packed(w))
 
 
-def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True):
+def conv2d_maxpool2(x, w, bias=None, act1=ACT_NONE, keep_y=True, proj=None):
     """(y, MaxPool2D(2)(y)) with y = act1(conv(x, w) + bias): ONE launch where the planned kernel is the fused Winograd kernel
     (its epilogue writes the pooled tensor too), conv + pooling launch otherwise -- decided below the C ABI.
-    keep_y=False returns the pooled tensor only."""
-    if not _is_h(x) and not _needs_grad(x, w, bias) and PRECISION in ("fp32", "fp16") and WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+    keep_y=False returns the pooled tensor only.
+    proj [3, Cout]: (sum_c proj[j, c] y[..., c], pooled) -- y itself is not written -- or None when the layer's planned kernel
+    cannot form the projection."""
+    fused = not _is_h(x) and not _needs_grad(x, w, bias) and PRECISION in ("fp32", "fp16") and WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+    if proj is not None:
+        if not fused or PRECISION != "fp32":
+            return None
+        return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, None, None, None, ACT_NONE, ALGO_AUTO, None, None, None, None, 0, True, proj=proj)
+    if fused:
         return _conv2d_raw(x, w, bias, 1, None, 1.0, act1, None, None, None, ACT_NONE, ALGO_AUTO, None, None, None, None, 0,
                            True if keep_y else "only")
     y = conv2d(x, w, bias, act1=act1)

@@ -216,6 +216,29 @@ extern "C" int64_t shdr_conv2d_workspace_bytes_f32(const shdr_conv2d_desc* d, in
   return (int64_t)(up + up256((size_t)16 * rows * (d->C1 + d->C2) * sizeof(float)) + up256((size_t)16 * rows * d->Cout * sizeof(float)));
 }
 
+// a split-operand launch never runs unscaled from the planned entry points: the range of a source that arrives without a slot is measured
+// into the scratch slots at the tail of the workspace (x1 of the bilinear prologue is the low-res tensor; bilinear weights are convex,
+// so its bound holds for the up-sampled one)
+static int measure_missing_ranges(const shdr_conv2d_desc* d, int has_residual, const float* x1, const float* x2, void* workspace,
+                                  const float*& x1_range, const float*& x2_range, void* stream) {
+  if (x1_range && (!x2 || x2_range)) return SHDR_OK;
+  SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL,
+               "conv2d_fwd_prepared: a split-operand layer without x ranges needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
+  float* slots = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shdr_conv2d_workspace_bytes_f32(d, has_residual) - kRangeScratch);
+  if (hipMemsetAsync(slots, 0, 2 * sizeof(float), S(stream)) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_fwd_prepared: memset failed");
+  const bool lowres = d->prologue == SHDR_PROLOGUE_BILINEAR2X;
+  const int64_t npix = (int64_t)d->N * (lowres ? d->H / 2 : d->H) * (lowres ? d->W / 2 : d->W);
+  if (!x1_range) {
+    if (int rcm = shdr_absmax_f32(x1, npix * d->C1, slots, stream)) return rcm;
+    x1_range = slots;
+  }
+  if (x2 && !x2_range) {
+    if (int rcm = shdr_absmax_f32(x2, npix * d->C2, slots + 1, stream)) return rcm;
+    x2_range = slots + 1;
+  }
+  return SHDR_OK;
+}
+
 extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
                                                    const float* bias, const float* scale, const float* shift, const float* residual, float* y,
                                                    float* y_pool, void* workspace, const float* x1_range, const float* x2_range,
@@ -225,22 +248,8 @@ extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, co
   SHDR_REQUIRE(d->pool == SHDR_POOL_MAX || d->pool == SHDR_POOL_AVG, SHDR_E_SHAPE, "conv2d_fwd_prepared: unknown pool kind");
   const int plan = plan_of(d, residual != nullptr);
   const bool avg = y_pool && d->pool == SHDR_POOL_AVG;
-  if (split_plan(plan) && (!x1_range || (x2 && !x2_range))) {
-    // unknown input range: measured (the split-operand kernels never run unscaled from here)
-    SHDR_REQUIRE(workspace && shdr::aligned16(workspace), SHDR_E_NULL,
-                 "conv2d_fwd_prepared: a split-operand layer without x ranges needs shdr_conv2d_workspace_bytes_f32 bytes of workspace");
-    float* slots = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shdr_conv2d_workspace_bytes_f32(d, residual != nullptr) - kRangeScratch);
-    if (hipMemsetAsync(slots, 0, 2 * sizeof(float), S(stream)) != hipSuccess) return shdr::fail(SHDR_E_LAUNCH, "conv2d_fwd_prepared: memset failed");
-    const bool lowres = d->prologue == SHDR_PROLOGUE_BILINEAR2X;           // x1 is the low-res tensor; bilinear weights are convex: same bound
-    const int64_t npix = (int64_t)d->N * (lowres ? d->H / 2 : d->H) * (lowres ? d->W / 2 : d->W);
-    if (!x1_range) {
-      if (int rcm = shdr_absmax_f32(x1, npix * d->C1, slots, stream)) return rcm;
-      x1_range = slots;
-    }
-    if (x2 && !x2_range) {
-      if (int rcm = shdr_absmax_f32(x2, npix * d->C2, slots + 1, stream)) return rcm;
-      x2_range = slots + 1;
-    }
+  if (split_plan(plan)) {
+    if (int rcm = measure_missing_ranges(d, residual != nullptr, x1, x2, workspace, x1_range, x2_range, stream)) return rcm;
   }
   const bool epilogue_range = split_plan(plan) || ((plan == SHDR_PLAN_MFMA || plan == SHDR_PLAN_DIRECT) && d->prologue == SHDR_PROLOGUE_NONE && y);
   if (y_range && !epilogue_range) {
@@ -325,6 +334,27 @@ extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, co
 }
 
 // the same without range slots: every split-operand layer measures its input range (one pass over x per source)
+// 1 if the planned kernel of the layer can write a projected output (shdr_conv2d_fwd_prepared_projected_f32)
+extern "C" int shdr_conv2d_projected_ok_f32(const shdr_conv2d_desc* d) {
+  if (!d || d->Cout != 64 || d->stride != 1 || plan_of(d, false) != SHDR_PLAN_X3) return 0;
+  if (d->cout_valid != 0 && d->cout_valid != 64) return 0;
+  return d->prologue == SHDR_PROLOGUE_NONE || (d->prologue == SHDR_PROLOGUE_BILINEAR2X && up2_in_kernel(d, SHDR_PLAN_X3));
+}
+
+// The planned forward call with a projected output (conv_x3.hip: shdr_conv2d_fwd_x3_projected_f32): y_proj[n,h,w,j] = sum_c proj[j][c] *
+// y[n,h,w,c], j < 3, from the epilogue that holds y; y and y_pool are written only when given.  Layers for which
+// shdr_conv2d_projected_ok_f32 is 0 are refused (the caller runs the convolution and the 1x1 map as two calls).
+extern "C" int shdr_conv2d_fwd_prepared_projected_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                                      const float* bias, const float* scale, const float* shift, const float* proj,
+                                                      float* y_proj, float* y, float* y_pool, void* workspace, const float* x1_range,
+                                                      const float* x2_range, float* y_range, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && proj && y_proj, SHDR_E_NULL, "conv2d_fwd_prepared_projected: null desc / x1 / prepared filter / proj / y_proj");
+  SHDR_REQUIRE(shdr_conv2d_projected_ok_f32(d), SHDR_E_SHAPE, "conv2d_fwd_prepared_projected: the planned kernel of this layer has no projected output");
+  SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SHDR_E_SHAPE, "conv2d_fwd_prepared_projected: the fused 2x2 pooling needs even Ho, Wo");
+  if (int rcm = measure_missing_ranges(d, 0, x1, x2, workspace, x1_range, x2_range, stream)) return rcm;
+  return shdr_conv2d_fwd_x3_projected_f32(d, x1, x2, prepared, bias, scale, shift, proj, y_proj, y, y_pool, x1_range, x2_range, y_range, stream);
+}
+
 extern "C" int shdr_conv2d_fwd_prepared_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                             const float* scale, const float* shift, const float* residual, float* y, float* y_pool,
                                             void* workspace, void* stream) {

@@ -79,6 +79,8 @@ struct X3Args {
   const unsigned* xr1;     // range slots of the two sources (bits of an upper bound of max |x|; null: no scaling)
   const unsigned* xr2;
   unsigned* yr;            // range slot of the output: atomicMax of max |y| (null: not wanted)
+  const float* proj;       // [3][64] or null: a linear map applied to the 64 output channels of every pixel in the epilogue ...
+  float* yproj;            // ... yproj[N,H,W,3][j] = sum_c proj[j][c] y[c] (shdr_conv2d_fwd_x3_projected_f32; Cout = 64)
 };
 
 // 2^T and 2^-T for the power of two that brings the larger of the two bounds into [2^10, 2^11); 1 for an empty, zero or non-finite bound
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   for (int mp = 0; mp < MT / 2; ++mp) {
     const int oh = oh0 + wave * MT + 2 * mp;                   // even row of the pair (H even whenever yp is given)
     if (oh >= a.H) continue;                                   // wave-uniform
+    float pj[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};      // a.proj: this lane's share (16 of the 64 couts) of the projected pixel, rows oh, oh + 1
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int cl = ni * 16 + 4 * fg;
@@ -436,6 +439,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         shdr::act_apply4<false>(v[r], a.act2);
         if (a.y && oh + r < a.H && ow < a.W)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
+        if (a.proj) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(a.proj + j * 64 + cl);
+            pj[r][j] += v[r][0] * q[0] + v[r][1] * q[1] + v[r][2] * q[2] + v[r][3] * q[3];
+          }
+        }
 #ifndef SHDR_ABL_NO_YM
         if (a.yr && oh + r < a.H) ym = fmaxf(fmaxf(fmaxf(fmaxf(ym, fabsf(v[r][0])), fabsf(v[r][1])), fabsf(v[r][2])), fabsf(v[r][3]));      // two v_max3_f32
 #endif
@@ -454,6 +464,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         }
         if (!(pc & 1) && ow < a.W)                               // lanes fi and fi ^ 1 hold columns pc and pc ^ 1
           *reinterpret_cast<f32x4*>(a.yp + ((size_t)(img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + n0 + cl) = m;
+      }
+    }
+    if (a.proj && a.final) {                                   // the four lane groups fg hold 16 couts each of the same pixel
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float t = pj[r][j];
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          pj[r][j] = t;
+        }
+        if (fg == 0 && oh + r < a.H && ow < a.W) {
+          float* o = a.yproj + ((size_t)(img * a.H + oh + r) * a.W + ow) * 3;
+          o[0] = pj[r][0]; o[1] = pj[r][1]; o[2] = pj[r][2];
+        }
       }
     }
   }
@@ -654,10 +680,13 @@ extern "C" int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float*
   return shdr_absmax_f32(x, n, prepared + 2, stream);
 }
 
-extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                                             const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
-                                             const float* x2_range, float* y_range, void* stream) {
-  SHDR_REQUIRE(d && x1 && prepared && (y || y_pool), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or neither y nor y_pool");
+static int x3_forward(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                      const float* scale, const float* shift, float* y, float* y_pool, const float* proj, float* y_proj, const float* x1_range,
+                      const float* x2_range, float* y_range, void* stream) {
+  SHDR_REQUIRE(d && x1 && prepared && (y || y_pool || y_proj), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or no output");
+  SHDR_REQUIRE((proj == nullptr) == (y_proj == nullptr), SHDR_E_NULL, "conv2d_x3: proj and y_proj come together");
+  SHDR_REQUIRE(!proj || (d->Cout == 64 && d->stride == 1 && shdr::aligned16(proj)), SHDR_E_SHAPE,
+               "conv2d_x3: the projected output takes a stride-1 layer with 64 output channels (one cout slice per block) and a 16-byte aligned map");
   SHDR_REQUIRE(!y_pool || (d->Ho % 2 == 0 && d->Wo % 2 == 0 && shdr::aligned16(y_pool)), SHDR_E_SHAPE, "conv2d_x3: the fused 2x2 max-pool needs even Ho, Wo");
   const bool up = d->prologue == SHDR_PROLOGUE_BILINEAR2X, rs = d->prologue == SHDR_PROLOGUE_RANGE_SCALE;
   SHDR_REQUIRE(d->prologue == SHDR_PROLOGUE_NONE || rs || (up && d->stride == 1 && d->C2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), SHDR_E_SHAPE,
@@ -684,6 +713,7 @@ extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const fl
   a.xr1 = reinterpret_cast<const unsigned*>(x1_range);
   a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);
   a.yr = reinterpret_cast<unsigned*>(y_range);
+  a.proj = proj; a.yproj = y_proj;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
@@ -708,6 +738,26 @@ extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const fl
     pk += x3_phase_floats(ph[i], Ct, d->Cout);
   }
   return SHDR_OK;
+}
+
+extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                             const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
+                                             const float* x2_range, float* y_range, void* stream) {
+  SHDR_REQUIRE(y || y_pool, SHDR_E_NULL, "conv2d_x3: neither y nor y_pool");
+  return x3_forward(d, x1, x2, prepared, bias, scale, shift, y, y_pool, nullptr, nullptr, x1_range, x2_range, y_range, stream);
+}
+
+// The same launch with a PROJECTED output: y_proj[n,h,w,j] = sum_c proj[j][c] * y[n,h,w,c] (proj: [3][64] floats, j < 3), written from
+// the epilogue that holds y in registers; y itself (and / or its pooled copy) is written only if asked for.  The tail of the
+// Hallucination-Net (hallucination_net.py:179-185: the 1x1 skip layer s1 on concat[u1, d1 / 255] followed by the 1x1 conv2 -- two linear
+// maps in a row) needs nothing but such a projection of u1's and of d1's 64 channels: their full-resolution tensors (1 GB each at
+// 16 x 512^2) are then never written nor read back.
+extern "C" int shdr_conv2d_fwd_x3_projected_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared,
+                                                const float* bias, const float* scale, const float* shift, const float* proj, float* y_proj,
+                                                float* y, float* y_pool, const float* x1_range, const float* x2_range, float* y_range,
+                                                void* stream) {
+  SHDR_REQUIRE(proj && y_proj, SHDR_E_NULL, "conv2d_x3_projected: null proj / y_proj");
+  return x3_forward(d, x1, x2, prepared, bias, scale, shift, y, y_pool, proj, y_proj, x1_range, x2_range, y_range, stream);
 }
 
 // The low-level entry point without range slots: the input is split as it stands (|x| must stay inside the fp16 range) unless

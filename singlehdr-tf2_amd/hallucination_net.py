@@ -24,11 +24,19 @@ class down1(Layer):
         self.conv1 = Conv2D(inChannels, outChannels, (3, 3), device=device)
         self.conv2 = Conv2D(outChannels, outChannels, (3, 3), device=device)
 
-    def call(self, x):
+    def call(self, x, proj=None):
+        """proj [3, outChannels]: return (pooled, sum_c proj[j, c] skip[..., c]) -- the only use the inference tail of the network has
+        for d1's skip tensor -- or None when the projection cannot be formed in the conv's epilogue"""
         if x.shape[-1] != self.conv1.kernel.shape[2]:   # zero-padded input (3 -> 4 channels)
             x = self.conv1.call_padded(x, cin_pad=x.shape[-1], act1=K.ACT_RELU)
         else:
             x = self.conv1(x, act1=K.ACT_RELU)
+        if proj is not None:
+            r = K.conv2d_maxpool2(x, self.conv2.kernel, self.conv2.bias, act1=K.ACT_RELU, proj=proj)
+            if r is not None:
+                return r[1], r[0], True
+            skip_layer, pooled = K.conv2d_maxpool2(x, self.conv2.kernel, self.conv2.bias, act1=K.ACT_RELU)
+            return pooled, skip_layer, False
         skip_layer, pooled = K.conv2d_maxpool2(x, self.conv2.kernel, self.conv2.bias, act1=K.ACT_RELU)
         return pooled, skip_layer
 
@@ -66,6 +74,12 @@ class up(Layer):
         scale, shift = self.norm1.folded()
         # inference: resize, conv, relu, folded BN, relu in ONE kernel -- the up-sampled tensor never reaches HBM
         return self.conv1.call_up2(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU)
+
+    def call_projected(self, x, proj):
+        """tape-free inference: sum_c proj[j, c] up(x)[..., c] from the same kernel's epilogue -- the block's own output is not written --
+        or None when the planned kernel cannot form it"""
+        scale, shift = self.norm1.folded()
+        return self.conv1.call_up2(x, act1=K.ACT_RELU, scale=scale, shift=shift, act2=K.ACT_RELU, proj=proj)
 
 
 class skipLayer(Layer):
@@ -111,10 +125,18 @@ class model(Layer):
             raise NotImplementedError("custom VGG_MEAN is not supported by the HIP preprocess kernel")
         input_layer, il = K.fork(input_layer)        # the 3-channel BGR image of the last skip layer and the padded encoder input
         bgr = K.vgg_preprocess(input_layer)          # x*255, RGB->BGR, - mean  (:149-153)
+        tail, d1_projected = None, False
         if K.native_fp16() and train:                # BASELINE configs[4]: fp16 feature maps (16 channels: the input gradient of
             x, d1 = self.d1(K.vgg_preprocess(il, 16, K.HALF))    # the first conv runs on the 16-channel MFMA tile)
         else:
-            x, d1 = self.d1(K.vgg_preprocess(il, 4))   # same, zero 4th channel: MFMA-friendly
+            # tape-free fp32 inference: the tail (below) uses d1's skip tensor only through a 64 -> 3 linear map, formed in the epilogue
+            # of d1.conv2 where its planned kernel can do that -- the 64-channel full-resolution skip tensor is then never written
+            if not train and K.PRECISION == "fp32" and not taping(input_layer, self.conv1.kernel, self.norm1.gamma):
+                tail = self._tail_projection()
+            if tail is not None:
+                x, d1, d1_projected = self.d1(K.vgg_preprocess(il, 4), proj=tail["skip_map"])
+            else:
+                x, d1 = self.d1(K.vgg_preprocess(il, 4))   # same, zero 4th channel: MFMA-friendly
         x, d2 = self.d2(x)
         x, d3 = self.d3(x)
         x, d4 = self.d4(x)
@@ -146,9 +168,38 @@ class model(Layer):
             # matrix, composed in float64 once per parameter version).  The 64-channel full-resolution tensor between them (1 GB
             # written and read back at 16 x 512^2) never exists.
             sc, sh = self.norm2.folded()
-            wc, bc = self._tail_filter(d1.shape[-1])
-            x = K.conv2d(self.u1(x, training), wc, bc, x2=d1, cout_valid=3, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:179-185)
+            if d1_projected:
+                # relu(sc (W_u u1 + W_d d1 / 255 + b) + sh) with both products as projections out of the producing kernels' epilogues
+                # (sc folded into the maps): neither u1's nor d1's 64-channel tensor (1 GB each at 16 x 512^2) reaches HBM
+                pu = self.u1.call_projected(x, tail["up_map"])
+                if pu is not None:
+                    x = K.affine_act(pu, shift=tail["const"], residual=d1, act=K.ACT_RELU)
+                else:                                  # u1 on another kernel: its half of the composed 1x1 map as a convolution
+                    x = K.conv2d(self.u1(x, training), tail["up_filter"], tail["bias"], cout_valid=3, scale=sc, shift=sh, residual=d1,
+                                 act2=K.ACT_RELU)
+            else:
+                wc, bc = self._tail_filter(d1.shape[-1])
+                x = K.conv2d(self.u1(x, training), wc, bc, x2=d1, cout_valid=3, scale=sc, shift=sh, act2=K.ACT_RELU)   # (:179-185)
         return self.s0(x, bgr, act1=K.ACT_RELU)                    # relu(s0(x, bgr)) (:188-190)
+
+    def _tail_projection(self):
+        """the composed tail (s1 -> conv2 -> folded norm2) split by source: [3, 64] maps for u1's and d1's 64 channels with norm2's scale
+        folded in (the d1 map also carries the 1 / 255), the constant sc (b1 W2 + b2) + sh, and u1's half as a 1x1 filter for the
+        fallback; cached per parameter version"""
+        c_skip = self.s1.conv1.kernel.shape[2] - 64
+        if c_skip != 64:
+            return None
+        wc, bc = self._tail_filter(c_skip)
+        sc, sh = self.norm2.folded()
+        key = (self._tail[0], id(sc), id(sh))
+        if getattr(self, "_tail_proj", None) is None or self._tail_proj[0] != key:
+            with torch.no_grad():
+                m = wc[0, 0, :, :3] * sc[:3]                                   # [128, 3]
+                up_filter = wc[:, :, :64, :].contiguous()
+                up_filter._shdr_const = True
+                self._tail_proj = (key, dict(up_map=m[:64].t().contiguous(), skip_map=m[64:].t().contiguous(),
+                                             const=(sc[:3] * bc + sh[:3]).contiguous(), up_filter=up_filter, bias=bc))
+        return self._tail_proj[1]
 
     def _tail_filter(self, c_skip):
         """composed 1x1 filter [1,1,64 + c_skip,16] (3 real output channels) and bias [3] of s1 -> conv2; the skip rows carry the 1/255"""

@@ -68,10 +68,15 @@ def test_refinement_net_parity(shdr, split_forced):
 def test_hallucination_net_parity(shdr, split_forced):
     m, p = build(shdr, "hal", 23)
     x = quantised_image(np.random.default_rng(3), (1, 64, 96, 3))
+    K = shdr._ops
+    before = K.PROJECTED_LAUNCHES[0]
     with torch.no_grad():                        # fused folded-BN / relu epilogues, conv + max-pool pairs in one launch
         y = host(m(dev(x), training=False))
     ref = nets.hal_forward(p, x)
     assert (y >= 0).all() and rel_err(y, ref) <= TOL
+    # on the split-operand plan (the benchmark's plan of these layers) the tail's 64 -> 3 maps come out of the epilogues of d1.conv2
+    # and u1.conv1 (shdr_conv2d_fwd_prepared_projected_f32): neither 64-channel full-resolution tensor is written
+    assert K.PROJECTED_LAUNCHES[0] - before == (2 if split_forced else 0)
 
 
 def test_linearization_net_parity(shdr, emor_table, split_forced):

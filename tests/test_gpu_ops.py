@@ -534,6 +534,38 @@ def test_backward_elementwise_kernels_track_their_output_range(shdr):
             assert g._shdr_range is big._shdr_range and float(g.abs().max()) <= float(big._shdr_range)
 
 
+def test_projected_output_of_the_split_operand_kernel(shdr, monkeypatch):
+    """shdr_conv2d_fwd_prepared_projected_f32: sum_c proj[j, c] y[..., c] from the epilogue that holds y (plain, with the fused 2x2
+    max-pool, and behind the bilinear 2x prologue) equals the 1x1 convolution of the written y (hallucination_net.py:179-185)"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    K = shdr._ops
+    rng = np.random.default_rng(21)
+    x = dev(f32(rng.normal(size=(2, 32, 48, 64))))
+    w = dev(f32(rng.normal(size=(3, 3, 64, 64)) / 24)).requires_grad_(True)
+    b = dev(f32(rng.normal(size=64)))
+    sc, sh = dev(f32(rng.uniform(0.5, 1.5, size=64))), dev(f32(rng.normal(size=64)))
+    proj = dev(f32(rng.normal(size=(3, 64))))
+    with torch.no_grad(), K.range_scope():
+        y, yp = K.conv2d_maxpool2(x, w, b, act1=K.ACT_RELU)
+        pj, pp = K.conv2d_maxpool2(x, w, b, act1=K.ACT_RELU, proj=proj)
+        want = torch.einsum("nhwc,jc->nhwj", y.double(), proj.double())
+        assert torch.equal(pp, yp) and float((pj.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        assert float(pp._shdr_range) >= float(pp.abs().max())
+        lo = dev(f32(rng.normal(size=(2, 16, 24, 64))))
+        yu = K.conv2d_up2(lo, w, b, act1=K.ACT_RELU, scale=sc, shift=sh, act2=K.ACT_RELU)
+        pu = K.conv2d_up2(lo, w, b, act1=K.ACT_RELU, scale=sc, shift=sh, act2=K.ACT_RELU, proj=proj)
+        want = torch.einsum("nhwc,jc->nhwj", yu.double(), proj.double())
+        assert float((pu.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # layers the split-operand plan does not take (128 output channels; the exact-fp32 plans) report it: the caller runs two convolutions
+        w128 = dev(f32(rng.normal(size=(3, 3, 64, 128)) / 24)).requires_grad_(True)
+        assert K.conv2d_maxpool2(x, w128, None, proj=dev(f32(rng.normal(size=(3, 128))))) is None
+        K.EXACT_FP32 = True
+        try:
+            assert K.conv2d_maxpool2(x, w, b, act1=K.ACT_RELU, proj=proj) is None
+        finally:
+            K.EXACT_FP32 = False
+
+
 WGRAD_X3_CASES = [("3x3_128_128", 2, 32, 32, 128, 0, 128, 3, 1), ("3x3_256_128_ragged", 1, 21, 37, 256, 0, 128, 3, 1),
                   ("3x3_two_sources_scaled", 2, 16, 24, 128, 128, 128, 3, 1), ("3x3_128_192", 1, 24, 24, 128, 0, 192, 3, 1),
                   ("3x3_stride2_256_128", 2, 32, 32, 256, 0, 128, 3, 2)]
