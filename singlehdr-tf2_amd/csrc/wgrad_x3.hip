@@ -290,7 +290,9 @@ extern "C" int shdr_x3_split_planes_f32(const float* x, int64_t n, const float* 
 extern "C" int shdr_conv2d_wgrad_x3_ok_f32(const shdr_conv2d_desc* d, int which) {
   if (!d || (which != 0 && !(which == 1 && d->C2 > 0))) return 0;
   const int Cx = which ? d->C2 : d->C1, cout = d->cout_valid > 0 ? d->cout_valid : d->Cout;
-  if (Cx % 64 || cout % 64 || cout != d->Cout || SHDR_ENV("SHDR_NO_X3") || SHDR_ENV("SHDR_NO_WGRAD_X3")) return 0;
+  // (a source whose channel count is not a multiple of the 64-channel tile -- the 96-channel front end of the Linearization-Net stem --
+  //  has its last tile loaded with zeros beyond Cx and stored up to ci_valid)
+  if (Cx % 32 || Cx < 64 || cout % 64 || cout != d->Cout || SHDR_ENV("SHDR_NO_X3") || SHDR_ENV("SHDR_NO_WGRAD_X3")) return 0;
   return (long)d->N * d->Ho * d->Wo < (1L << 31) && (long)d->N * d->H * d->W * Cx < (1L << 32) ? 1 : 0;
 }
 

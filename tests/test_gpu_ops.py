@@ -568,7 +568,7 @@ def test_projected_output_of_the_split_operand_kernel(shdr, monkeypatch):
 
 WGRAD_X3_CASES = [("3x3_128_128", 2, 32, 32, 128, 0, 128, 3, 1), ("3x3_256_128_ragged", 1, 21, 37, 256, 0, 128, 3, 1),
                   ("3x3_two_sources_scaled", 2, 16, 24, 128, 128, 128, 3, 1), ("3x3_128_192", 1, 24, 24, 128, 0, 192, 3, 1),
-                  ("3x3_stride2_256_128", 2, 32, 32, 256, 0, 128, 3, 2)]
+                  ("3x3_stride2_256_128", 2, 32, 32, 256, 0, 128, 3, 2), ("7x7_stride2_96_64_lin_stem", 2, 40, 48, 96, 0, 64, 7, 2)]
 
 
 @pytest.mark.parametrize("case", WGRAD_X3_CASES, ids=[c[0] for c in WGRAD_X3_CASES])
@@ -606,7 +606,7 @@ def test_split_operand_weight_gradient(shdr, case, monkeypatch):
     # the plan: this layer does take the split-operand kernel (and the exact switch does not)
     lib, d = shdr._lib.load(), K._conv_desc((n, h, w, c1), (k, k, c1 + c2, cout), stride, c2, x2s, None)
     import ctypes
-    assert lib.shdr_conv2d_wgrad_x3_ok_f32(ctypes.byref(d), 0) == 1 and min(c1, cout) >= K.WGRAD_X3_MIN_CH
+    assert lib.shdr_conv2d_wgrad_x3_ok_f32(ctypes.byref(d), 0) == 1 and (min(c1, cout) >= K.WGRAD_X3_MIN_CH or (k * k >= 25 and min(c1, cout) >= 64))
     acc = torch.full((k, k, c1 + c2, cout), 2.0, device="cuda")               # `out=`: accumulates into a flat-gradient view
     g = K.conv2d_wgrad(dev(x), None if x2 is None else dev(x2), dev(dz), (k, k, c1 + c2, cout), stride, x2s)
     K.conv2d_wgrad(dev(x), None if x2 is None else dev(x2), dev(dz), (k, k, c1 + c2, cout), stride, x2s, out=acc)
