@@ -848,7 +848,7 @@ def conv2d_wgrad(x, x2, dz, w_shape, stride=1, x2_scale=1.0, out=None):
     # split passes included) against the Winograd-domain fp32 kernel: 512 -> 512 at 32^2 0.85 -> 0.60 ms, 512 -> 256 at 64^2 1.61 -> 1.06,
     # 256 -> 256 at 64^2 0.85 -> 0.62, 256 -> 128 at 128^2 1.59 -> 1.27, 128 -> 128 at 128^2 0.78 -> 0.72 (215-290 TFLOP/s in fp32 layer
     # FLOPs); 1x1 layers do too little arithmetic per element for the two split passes (0.33 -> 0.43 ms at 256 + 256 -> 256) and stay exact
-    # (a 7x7 layer does 49 taps of arithmetic per split element: the stem of the Linearization-Net, 96 -> 64, 2.97 -> 1.3 ms at 32 x 256^2)
+    # (a 7x7 layer does 49 taps of arithmetic per split element: the stem of the Linearization-Net, 96 -> 64, 3.0 -> 1.9 ms at 32 x 256^2, split passes included)
     wide = min(c1, c2 or c1, cout) >= WGRAD_X3_MIN_CH or (kh * kw >= 25 and min(c1, c2 or c1, cout) >= 64)
     if (PRECISION == "fp32" and not EXACT_FP32 and WINOGRAD and kh * kw >= 9 and wide and cin == c1 + c2
             and cout == dz.shape[3] and x.numel() % 8 == 0 and dz.numel() % 8 == 0 and (x2 is None or x2.numel() % 8 == 0)):
