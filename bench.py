@@ -487,19 +487,23 @@ def main():
 
             orig_cp = K.conv2d_maxpool2
 
-            def timed_conv_pool(x, w, bias=None, act1=0):
+            def timed_conv_pool(x, w, bias=None, act1=0, keep_y=True, proj=None):
                 # conv + MaxPool2D(2) pairs of the Hallucination-Net encoder: one launch of the fused Winograd kernel where
                 # it applies (timed here as that launch), otherwise conv2d() [recorded by timed_conv] + maxpool2
                 plan = K.conv2d_plan(tuple(x.shape), tuple(w.shape)) if K.WINOGRAD and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 else None
                 if plan not in ("fused", "x3"):            # direct plans: conv2d() [recorded by timed_conv] + maxpool2
+                    if proj is not None:
+                        return None                        # (the caller then runs the convolution and the 1x1 map as two calls)
                     y = timed_conv(x, w, bias, act1=act1)
-                    return y, K.maxpool2(y)
+                    return (y, K.maxpool2(y)) if keep_y else K.maxpool2(y)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                out = orig_cp(x, w, bias, act1)
+                out = orig_cp(x, w, bias, act1, keep_y, proj)
                 e1.record()
+                if out is None:                            # projection refused by the library: nothing was launched
+                    return None
                 records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", conv_flops(x, w, 1, None), e0, e1,
-                                "%dx%d %d+0->%d k3 s1 +pool" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3]), False))
+                                "%dx%d %d+0->%d k3 s1 +pool%s" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3], " +proj" if proj is not None else ""), False))
                 return out
 
             orig_ap = K.conv2d_avgpool2
@@ -529,11 +533,15 @@ def main():
                 n, h, wd, c = x.shape
                 plan = K.conv2d_plan((n, 2 * h, 2 * wd, c), tuple(w.shape)) if K.WINOGRAD else None
                 if plan not in ("fused", "x3"):
+                    if kw.get("proj") is not None:
+                        return None
                     return timed_conv(K.resize2x(x), w, bias, **kw)      # direct plans: the up-sampled tensor goes through memory
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = orig_up(x, w, bias, **kw)
                 e1.record()
+                if out is None:
+                    return None
                 records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
                                 "%dx%d(x2) %d+0->%d k3 s1 +bilinear" % (h, wd, c, w.shape[3]), False))
                 return out
