@@ -406,7 +406,7 @@ extern "C" int shdr_conv2d_fwd_f16(const shdr_conv2d_desc* d, const void* x1, co
   a.cout_valid = cout_valid;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // narrow full-resolution layers (<= 32 channels per tap, 16 / 32 couts): raw patch + resident filter in LDS (conv_f16_patch.hip)
-  if (shdr_conv2d_patch_ok_f16(d) && SHDR_ENV("SHDR_NO_PATCH") == nullptr)
+  if (shdr_conv2d_patch_ok_f16(d) && (y_is_f32 || d->act1 != SHDR_ACT_TANH) && SHDR_ENV("SHDR_NO_PATCH") == nullptr)
     return shdr_conv2d_fwd_patch_f16(d, x1, x2, wp, bias, y, y_is_f32, stream);
   // wide 3x3 layers: raw patch per 32-channel chunk instead of nine im2col stagings (conv_f16_w3.hip)
   if (!y_is_f32 && shdr_conv2d_w3_ok_f16(d) && SHDR_ENV("SHDR_NO_W3") == nullptr) return shdr_conv2d_fwd_w3_f16(d, x1, x2, wp, bias, y, stream);

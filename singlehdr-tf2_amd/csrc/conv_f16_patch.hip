@@ -209,15 +209,21 @@ __global__ __launch_bounds__(256) void conv_f16_patch_kernel(const PatchArgs a) 
       for (int ni = 0; ni < NT; ++ni) {
         const int co = ni * 16 + 4 * fg;
         f32x4 v = acc[mi][ni];
-        if (a.y32) {
+        if (a.y32) {                                             // the fp32 heads (tanh lives here only: shdr_internal.h act_apply4)
+          if (co >= a.cout_valid) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (co + e < a.cout_valid) a.y32[pix * a.cout_valid + co + e] = shdr::act_apply(v[e] + (a.bias ? a.bias[co + e] : 0.f), a.act1);
+            if (a.bias && co + e < a.cout_valid) v[e] += a.bias[co + e];
+          shdr::act_apply4<true>(v, a.act1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.cout_valid) a.y32[pix * a.cout_valid + co + e] = v[e];
         } else {
           v += bias_r[ni];
+          shdr::act_apply4<false>(v, a.act1);                    // (fp16 outputs with tanh go to the general kernel: shdr_conv2d_fwd_f16)
           f16x4 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = (_Float16)shdr::act_apply(v[e], a.act1);
+          for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
           // 16 lanes x 8 bytes at a stride of Cout * 2 bytes: with 16 / 32 couts the four lane groups of a pixel complete its
           // 32- / 64-byte row in one instruction
           *reinterpret_cast<f16x4*>(a.y16 + pix * a.Cout + co) = h;
@@ -280,6 +286,7 @@ extern "C" int shdr_conv2d_fwd_patch_f16(const shdr_conv2d_desc* d, const void* 
                                          void* y, int y_is_f32, void* stream) {
   SHDR_REQUIRE(d && x1 && wp && y, SHDR_E_NULL, "conv2d_patch_f16: null desc/x1/wp/y");
   SHDR_REQUIRE(shdr_conv2d_patch_ok_f16(d), SHDR_E_SHAPE, "conv2d_patch_f16: layer shape not taken by the patch kernel");
+  SHDR_REQUIRE(y_is_f32 || d->act1 != SHDR_ACT_TANH, SHDR_E_SHAPE, "conv2d_patch_f16: tanh is compiled into the fp32-output (head) path only");
   SHDR_REQUIRE((d->C2 == 0) == (x2 == nullptr), SHDR_E_NULL, "conv2d_patch_f16: x2 must be given iff C2 > 0");
   const int cout_valid = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   SHDR_REQUIRE(cout_valid <= d->Cout && (y_is_f32 || cout_valid == d->Cout), SHDR_E_SHAPE, "conv2d_patch_f16: bad cout_valid");

@@ -169,9 +169,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
         const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + cl);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
       }
+      shdr::act_apply4<false>(v, a.act1);                      // (no tanh here: shdr_conv2d_w3_ok_f16; shdr_internal.h act_apply4)
       f16x4 h;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (_Float16)shdr::act_apply(v[e], a.act1);
+      for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
       *reinterpret_cast<f16x4*>(stage + r * RS + cl) = h;
     }
   }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
 
 extern "C" int shdr_conv2d_w3_ok_f16(const shdr_conv2d_desc* d) {
   if (!d || d->stride != 1 || d->KH != 3 || d->KW != 3 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
-  if (d->C1 % 32 || d->C2 % 32 || d->Cout % 64) return 0;
+  if (d->C1 % 32 || d->C2 % 32 || d->Cout % 64 || d->act1 == SHDR_ACT_TANH) return 0;      // (tanhf is not compiled into this kernel)
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv != d->Cout) return 0;
   // enough blocks to fill the chip: the deepest, smallest maps stay on the 128 x 128 implicit-GEMM tiles
