@@ -395,9 +395,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     const int cl = ni * 16 + 4 * fg;
-    bias_r[ni] = (a.bias && a.final) ? *reinterpret_cast<const f32x4*>(a.bias + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    scale_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.scale + ep0 + cl) : (f32x4){1.f, 1.f, 1.f, 1.f};
-    shift_r[ni] = (a.scale && a.final) ? *reinterpret_cast<const f32x4*>(a.shift + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool cv = ep0 + cl < a.Cout;                           // (false only in the zero half of a 32-cout layer's slice: nothing loaded, nothing stored)
+    bias_r[ni] = (a.bias && a.final && cv) ? *reinterpret_cast<const f32x4*>(a.bias + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    scale_r[ni] = (a.scale && a.final && cv) ? *reinterpret_cast<const f32x4*>(a.scale + ep0 + cl) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    shift_r[ni] = (a.scale && a.final && cv) ? *reinterpret_cast<const f32x4*>(a.shift + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // the partial sums of the earlier phases of a stride-2 layer (yin), batched in front of the stores for the same reason
   f32x4 yin_r[MT / 2][NT][2];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         shdr::act_apply4<false>(v[r], a.act1);
         if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
         shdr::act_apply4<false>(v[r], a.act2);
-        if (a.y && oh + r < a.H && ow < a.W)
+        if (a.y && oh + r < a.H && ow < a.W && n0 + cl < a.Cout)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
         if (a.proj) {
 #pragma unroll
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
             m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
           }
         }
-        if (!(pc & 1) && ow < a.W)                               // lanes fi and fi ^ 1 hold columns pc and pc ^ 1
+        if (!(pc & 1) && ow < a.W && n0 + cl < a.Cout)           // lanes fi and fi ^ 1 hold columns pc and pc ^ 1
           *reinterpret_cast<f32x4*>(a.yp + ((size_t)(img * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.Cout + n0 + cl) = m;
       }
     }
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
   const int ntaps = TH * TW;
   const int nunits = (Ct >> 5) * ntaps;
-  const long total = (long)(Cout / 64) * nunits * 64 * 32;
+  const long total = (long)((Cout + 63) / 64) * nunits * 64 * 32;      // (a 32-cout layer fills half of its one 64-cout slice with zeros)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int k = (int)(e & 31), co = (int)((e >> 5) & 63);
     const long t = e >> 11;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
     const int ta = t2 / TW, tb = t2 - TW * ta;
     const int tap = (p0 + step * ta) * KWF + (q0 + step * tb);
     const int ch = chunk * 32 + k;
-    float v = w[((size_t)tap * Ct + ch) * Cout + nb * 64 + co] * s;
+    float v = nb * 64 + co < Cout ? w[((size_t)tap * Ct + ch) * Cout + nb * 64 + co] * s : 0.0f;
     if (ch >= C1) v *= x2_scale;
     const _Float16 h = (_Float16)v;
     _Float16* o = out + ((size_t)(nb * nunits + u) * 2) * IMG_HALVES + co * 32 + k;
@@ -564,7 +565,7 @@ int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
     for (int q0 = 0; q0 < 2; ++q0) ph[n++] = X3Phase{(d->KH - p0 + 1) / 2, (d->KW - q0 + 1) / 2, p0, q0, 2, p0 - d->pad_t, q0 - d->pad_l};
   return n;
 }
-inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * Cout; }    // two fp16 images
+inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * ((Cout + 63) / 64 * 64); }    // two fp16 images
 
 template <bool UP, int KH, int KW>
 int launch_x3(const X3Args& a, hipStream_t st) {
@@ -585,7 +586,9 @@ int launch_x3(const X3Args& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
-  if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout % 64) return 0;
+  // Cout 32 (the 64 -> 32 and 32 + 32 -> 32 decoder layers of the U-Nets, dequantization_net.py:17-29): one 64-cout slice, half of it zero
+  // filter columns that are neither biased nor stored -- twice the arithmetic of the layer and still 1.3x the exact fp32 kernel
+  if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || (d->Cout % 64 && (d->Cout != 32 || d->stride != 1 || SHDR_ENV("SHDR_NO_X3_COUT32")))) return 0;
   const int cv = d->cout_valid > 0 ? d->cout_valid : d->Cout;
   if (cv != d->Cout || d->w_batch_stride != 0 || d->y_pix_stride > 1) return 0;
   if ((long)d->N * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1L << 31)) return 0;
@@ -607,14 +610,14 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
       return 0;
   }
   // enough blocks to fill the chip: the deepest, smallest maps stay on the fused Winograd kernel (8 x 16 tiles)
-  const long blocks = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 64);
+  const long blocks = (long)d->N * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * ((d->Cout + 63) / 64);
   long min_blocks = 192;          // measured (tools/dbg/x3_threshold.py): 256 blocks 1.24-1.28x the fused Winograd kernel, 128 blocks 0.75x
   if (const char* e = SHDR_ENV("SHDR_X3_MIN_BLOCKS")) min_blocks = atol(e);
   return blocks >= min_blocks ? 1 : 0;
 }
 
 extern "C" int64_t shdr_conv2d_x3_filter_elems_f32(const shdr_conv2d_desc* d) {
-  if (!d || d->C1 <= 0 || (d->C1 + d->C2) % 32 || d->Cout % 64 || (d->stride != 1 && d->stride != 2)) return -1;
+  if (!d || d->C1 <= 0 || (d->C1 + d->C2) % 32 || (d->Cout % 64 && d->Cout != 32) || (d->stride != 1 && d->stride != 2)) return -1;
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
   int64_t total = 0;
@@ -631,8 +634,8 @@ extern "C" int shdr_conv2d_x3_prepare_filter_f32(const shdr_conv2d_desc* d, cons
 extern "C" int shdr_conv2d_x3_prepare_filter_premax_f32(const shdr_conv2d_desc* d, const float* w, float* prepared, int premax, void* stream) {
   SHDR_REQUIRE(d && w && prepared, SHDR_E_NULL, "conv2d_x3_prepare_filter: null pointer");
   const int Ct = d->C1 + d->C2;
-  SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && d->C1 % 32 == 0 && d->Cout > 0 && d->Cout % 64 == 0, SHDR_E_SHAPE,
-               "conv2d_x3_prepare_filter: need C %% 32 == 0, Cout %% 64 == 0");
+  SHDR_REQUIRE(Ct > 0 && Ct % 32 == 0 && d->C1 % 32 == 0 && d->Cout > 0 && (d->Cout % 64 == 0 || d->Cout == 32), SHDR_E_SHAPE,
+               "conv2d_x3_prepare_filter: need C %% 32 == 0, Cout %% 64 == 0 (or Cout 32)");
   SHDR_REQUIRE(shdr::aligned16(prepared), SHDR_E_ALIGN, "conv2d_x3_prepare_filter: prepared must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const float x2s = d->C2 > 0 ? d->x2_scale : 1.0f;
@@ -648,7 +651,7 @@ extern "C" int shdr_conv2d_x3_prepare_filter_premax_f32(const shdr_conv2d_desc* 
       const int gmax = shdr::stream_grid(nw) < 64 ? shdr::stream_grid(nw) : 64;
       hipLaunchKernelGGL(x3_absmax_kernel, dim3(gmax), dim3(256), 0, st, w, nw, reinterpret_cast<unsigned*>(out));
     }
-    const long np = (long)ph[i].th * ph[i].tw * Ct * d->Cout;
+    const long np = (long)ph[i].th * ph[i].tw * Ct * ((d->Cout + 63) / 64 * 64);
     hipLaunchKernelGGL(x3_pack_kernel, dim3(shdr::stream_grid(np)), dim3(256), 0, st, w, out, reinterpret_cast<_Float16*>(out + X3_HEADER_FLOATS), Ct,
                        d->C1, d->Cout, x2s, d->KW, ph[i].th, ph[i].tw, ph[i].p0, ph[i].q0, ph[i].step);
     out += x3_phase_floats(ph[i], Ct, d->Cout);
@@ -708,7 +711,7 @@ static int x3_forward(const shdr_conv2d_desc* d, const float* x1, const float* x
   a.tiles_x = (a.W + 15) / 16;
   a.tiles_y = (a.H + 15) / 16;
   a.nblk_m = a.N * a.tiles_x * a.tiles_y;
-  a.nblk_n = a.Cout / 64;
+  a.nblk_n = (a.Cout + 63) / 64;
   a.act1 = d->act1; a.act2 = d->act2;
   a.xr1 = reinterpret_cast<const unsigned*>(x1_range);
   a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);

@@ -638,6 +638,7 @@ AVGPOOL_CASES = [  # name, n, h, w, cin, cout, k, expected plan
     ("x3n_7x7_16_16", 2, 32, 48, 16, 16, 7, "x3n"), ("x3n_5x5_32_32_ragged_tiles", 1, 38, 26, 32, 32, 5, "x3n"),
     ("x3n_3x3_16_32", 1, 16, 16, 16, 32, 3, "x3n"), ("x3_3x3_64_64", 2, 32, 48, 64, 64, 3, "x3"),
     ("x3_3x3_128_128_ragged_tiles", 1, 22, 38, 128, 128, 3, "x3"), ("fallback_3x3_48_48", 1, 12, 20, 48, 48, 3, None),
+    ("x3_3x3_64_32_half_slice", 2, 22, 38, 64, 32, 3, "x3"),        # a 32-cout layer on one 64-cout slice (deq / ref u2.conv1)
 ]
 
 
@@ -660,6 +661,37 @@ def test_conv2d_avgpool2_pair(shdr, case, monkeypatch):
     assert torch.equal(y, K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU))
     assert tuple(yp.shape) == (n, h // 2, w // 2, cout) and torch.equal(yp, K.avgpool2(y))
     np.testing.assert_allclose(host(yp), ops.avg_pool2(host(y).astype(np.float64)), rtol=1e-6, atol=1e-7)
+
+
+def test_conv2d_x3_thirty_two_couts(shdr, monkeypatch):
+    """the 64 -> 32 and 32 + 32 -> 32 decoder layers of the U-Nets (dequantization_net.py:17-29) on the split-operand kernel: one 64-cout
+    slice whose upper half is zero filter columns, neither biased nor stored; plain, two sources, behind the bilinear prologue, input
+    gradient -- vs the float64 oracle at the exact kernels' bar"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    K = shdr._ops
+    rng = np.random.default_rng(77)
+    n, h, w = 2, 26, 38
+    x = f32(rng.normal(size=(n, h, w, 64)))
+    wt = f32(rng.normal(size=(3, 3, 64, 32)) / 24)
+    b = f32(rng.normal(size=32) * 0.1)
+    assert K.conv2d_plan((n, h, w, 64), wt.shape) == "x3"
+    y = K.conv2d(dev(x), dev(wt), dev(b), act1=K.ACT_LRELU)
+    assert tuple(y.shape) == (n, h, w, 32) and rel_err(host(y), oracle_conv(x, wt, b, act1=2)) <= TOL
+    assert float(y._shdr_range) == float(y.abs().max())
+    xa, xb = f32(rng.normal(size=(n, h, w, 32))), f32(rng.normal(size=(n, h, w, 32)))
+    assert K.conv2d_plan((n, h, w, 32), wt.shape, c2=32) == "x3"
+    y2 = K.conv2d(dev(xa), dev(wt), dev(b), x2=dev(xb), act1=K.ACT_LRELU)
+    assert rel_err(host(y2), oracle_conv(np.concatenate([xa, xb], -1), wt, b, act1=2)) <= TOL
+    lo = f32(rng.normal(size=(n, h // 2, w // 2, 64)))
+    with torch.no_grad():
+        yu = K.conv2d_up2(dev(lo), dev(wt), dev(b), act1=K.ACT_LRELU)
+        want = K.conv2d(K.resize2x(dev(lo)), dev(wt), dev(b), act1=K.ACT_LRELU)
+    assert float((yu - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # the input gradient of a 32 -> 64 layer is a 64 -> 32 convolution with the flipped filter: the same kernel
+    wf = f32(rng.normal(size=(3, 3, 32, 64)) / 17)
+    dz = f32(rng.normal(size=(n, h, w, 64)))
+    dx = K.conv2d_dgrad(dev(dz), dev(wf), (n, h, w, 32), 32, 0, 0)
+    assert rel_err(host(dx), oracle_conv(dz, np.ascontiguousarray(wf[::-1, ::-1].transpose(0, 1, 3, 2)))) <= TOL
 
 
 X3N_CASES = [  # name, n, h, w, c1, c2, cout (filter width), cout_valid, k, act1, residual
