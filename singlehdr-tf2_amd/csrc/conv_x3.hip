@@ -79,6 +79,9 @@ struct X3Args {
   const unsigned* xr1;     // range slots of the two sources (bits of an upper bound of max |x|; null: no scaling)
   const unsigned* xr2;
   unsigned* yr;            // range slot of the output: atomicMax of max |y| (null: not wanted)
+  int nphase;              // MP kernel (the 7x7 / stride-2 stem in ONE launch): phase p runs pth[p] x ptw[p] taps at input offset (pbh[p], pbw[p]) with
+  int pth[4], ptw[4], pbh[4], pbw[4];      // the packed sub-filter pwp[p]; all phases accumulate in the block's registers
+  const _Float16* pwp[4];
   const float* proj;       // [3][64] or null: a linear map applied to the 64 output channels of every pixel in the epilogue ...
   float* yproj;            // ... yproj[N,H,W,3][j] = sum_c proj[j][c] y[c] (shdr_conv2d_fwd_x3_projected_f32; Cout = 64)
 };
@@ -153,11 +156,16 @@ __device__ __forceinline__ int pcol(int fi) { return fi < 4 ? fi : (fi >= 12 ? f
 // divided by it -- both exact.  This matters at both ends: activations beyond the fp16 range, and the output gradients dz of the
 // training steps far below it (max |dz| 3e-8 ... 2e-2 in the joint step: unscaled, their high terms are fp16 subnormals and the
 // parameter gradient differed from the exact-fp32 kernels' by 3e-5; scaled, by the run-to-run noise).
-template <bool UP, int KH, int KW>
+// MP (with KH = KW = 4, the largest phase): the four parity phases of a 7x7 / stride-2 layer in ONE launch -- a phase loop around the chunk loop
+// with the tap counts, the input offset and the sub-filter of each phase taken from the argument arrays; the partial sums stay in the
+// accumulators (the four-launch form wrote and re-read them three times: 3 x 2 x N Ho Wo Cout floats).  The patch geometry is that of the
+// 4 x 4 phase for every phase: a 3-tap dimension loads one row / column it does not use.
+template <bool UP, int KH, int KW, bool MP = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   using G = X3G<KH, KW>;
   constexpr int PWID = G::PWID, PPIX = G::PPIX, PJ = G::PJ, PATCH_HALVES = G::PATCH_HALVES, NTAPS = KH * KW;
   static_assert(!UP || (KH == 3 && KW == 3), "the up-sampling prologue belongs to the 3 x 3 stride-1 form");
+  static_assert(!MP || (!UP && KH == 4 && KW == 4), "the phase loop is built on the 4 x 4 patch geometry");
   extern __shared__ __attribute__((aligned(16))) _Float16 xsm[];
   // LDS regions as expressions of the __shared__ symbol (pointer VARIABLES captured by the lambdas below lost their address space: the
   // compiler kept them as 64-bit generic pointers in scratch and reloaded them inside the tap loop)
@@ -180,16 +188,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   // ---- patch geometry (fixed per block): piece p = tid + 256 j -> (patch pixel, float4 of the 32-channel chunk) ----------------
   int ppix[PJ];                                                // pixel index in the image tensor, -1: padding / beyond the patch
   int pdst[PJ];                                                // half offset of the 8-byte destination inside an image
+  auto patch_geometry = [&](int bh, int bw) __attribute__((always_inline)) {                  // (MP: once per phase)
 #pragma unroll
-  for (int j = 0; j < (UP ? 0 : PJ); ++j) {
-    const int p = tid + 256 * j;
-    const int pix = p >> 3, q = p & 7;
-    const int py = pix / PWID, px = pix - py * PWID;
-    const int ih = a.in_s * (oh0 + py) + a.bh, iw = a.in_s * (ow0 + px) + a.bw;
-    const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-    ppix[j] = ok ? (img * a.Hin + ih) * a.Win + iw : -1;
-    pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ sx(px)) + 4 * (q & 1) : -1;
-  }
+    for (int j = 0; j < (UP ? 0 : PJ); ++j) {
+      const int p = tid + 256 * j;
+      const int pix = p >> 3, q = p & 7;
+      const int py = pix / PWID, px = pix - py * PWID;
+      const int ih = a.in_s * (oh0 + py) + bh, iw = a.in_s * (ow0 + px) + bw;
+      const bool ok = pix < PPIX && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      ppix[j] = ok ? (img * a.Hin + ih) * a.Win + iw : -1;
+      pdst[j] = pix < PPIX ? pix * 32 + 8 * ((q >> 1) ^ sx(px)) + 4 * (q & 1) : -1;
+    }
+  };
+  if (!MP) patch_geometry(a.bh, a.bw);
   // UP: low-res pieces of this thread: piece p = tid + 256 j -> (low-res patch pixel, float4)
   int lpix[LRJ];
   if (UP) {
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     }
   }
   const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
-  const int nunits = nch * NTAPS;
+  int nunits = nch * NTAPS;                                    // (MP: per phase)
   f32x4 pr[PJ];
   auto load_lr = [&](int c) __attribute__((always_inline)) {                                  // UP: low-res chunk c -> the first LRJ registers
 #pragma unroll
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   };
   // ---- filter units: 8 KB per tap = 512 pieces of 16 bytes, two per thread --------------------------------------------------------
   constexpr int FJ = 2;
-  const _Float16* wbase = a.wp + (size_t)pn * nunits * UNIT_HALVES;
+  const _Float16* wbase = a.wp + (size_t)pn * nunits * UNIT_HALVES;      // (MP: per phase)
   int fdst[FJ];
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
@@ -317,9 +328,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     b_rd[ni] = row * 32 + 8 * (fg ^ f4(row));
   }
 
+  int kh_n = KH, kw_n = KW;                                    // taps of the phase (MP)
+#pragma unroll 1
+  for (int phase = 0; phase < (MP ? a.nphase : 1); ++phase) {
+  if (MP) {
+    kh_n = a.pth[phase];
+    kw_n = a.ptw[phase];
+    nunits = nch * kh_n * kw_n;
+    wbase = a.pwp[phase] + (size_t)pn * nunits * UNIT_HALVES;
+    patch_geometry(a.pbh[phase], a.pbw[phase]);
+    if (phase > 0) __syncthreads();                            // every wave has read the last tap of the previous phase (patch and filter buffers)
+  }
   load_patch(0);
   load_filt(0);
-  x3_range_scale(a.xr1, a.xr2, xs, ixs);
+  if (!MP || phase == 0) x3_range_scale(a.xr1, a.xr2, xs, ixs);
   if (UP) {
     park_lr();
     __syncthreads();
@@ -330,10 +352,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) load_patch(c + 1);                        // lands under the taps of this chunk
 #pragma unroll 1
-    for (int kh = 0; kh < KH; ++kh) {
+    for (int kh = 0; kh < (MP ? kh_n : KH); ++kh) {
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) {                        // unrolled: acol[kw] stays a register
-        const int u = c * NTAPS + kh * KW + kw;
+        if (MP && kw >= kw_n) continue;                        // (block-uniform)
+        const int u = MP ? (c * kh_n + kh) * kw_n + kw : c * NTAPS + kh * KW + kw;
         __syncthreads();                                       // unit u (and, at the first tap, the patch) is in LDS; buffer (u + 1) & 1 is free
         if (u + 1 < nunits) load_filt(u + 1);
         const _Float16* F = filt + (u & 1) * UNIT_HALVES;
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       store_patch();                                           // visible after the barrier at the top of the next tap loop
     }
   }
+  }                                                            // phase loop
 
   // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts); the 2 x 2 pooling
   //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
@@ -567,19 +591,19 @@ int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
 }
 inline int64_t x3_phase_floats(const X3Phase& p, int Ct, int Cout) { return X3_HEADER_FLOATS + (int64_t)p.th * p.tw * Ct * ((Cout + 63) / 64 * 64); }    // two fp16 images
 
-template <bool UP, int KH, int KW>
+template <bool UP, int KH, int KW, bool MP = false>
 int launch_x3(const X3Args& a, hipStream_t st) {
   constexpr int lds = UP ? X3G<KH, KW>::LDS_BYTES_UP : X3G<KH, KW>::LDS_BYTES;
   static bool attr_done[shdr::kMaxDevices] = {};
   const int dev_slot = shdr::device_slot();
   if (!attr_done[dev_slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<UP, KH, KW, MP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return shdr::fail(SHDR_E_ARCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[dev_slot] = true;
   }
   const long nblk = (long)a.nblk_m * a.nblk_n;
   if (nblk > 0x7fffffffL) return shdr::fail(SHDR_E_SHAPE, "conv2d_x3: grid of %ld blocks", nblk);
-  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_x3_kernel<UP, KH, KW, MP>), dim3((unsigned)nblk), dim3(256), lds, st, a);
   return shdr::check_launch("conv_x3_kernel");
 }
 
@@ -723,6 +747,24 @@ static int x3_forward(const shdr_conv2d_desc* d, const float* x1, const float* x
   SHDR_REQUIRE(n == 1 || y, SHDR_E_NULL, "conv2d_x3: the phases of a stride-2 layer accumulate in y");
   const int Ct = d->C1 + d->C2;
   const float* pk = prepared;
+  if (n == 4 && SHDR_ENV("SHDR_X3_STEM_PHASE_LAUNCHES") == nullptr) {
+    // the stride-2 stem in ONE launch: the phases' packed sub-filters share the scale 2^S (each header's maximum is taken over the whole
+    // filter), the partial sums stay in registers
+    a.hdr = pk;
+    a.in_s = ph[0].step;
+    a.nphase = 4;
+    for (int i = 0; i < 4; ++i) {
+      SHDR_REQUIRE(ph[i].th <= 4 && ph[i].tw <= 4 && ph[i].step == ph[0].step, SHDR_E_SHAPE, "conv2d_x3: unexpected phase geometry");
+      a.pth[i] = ph[i].th; a.ptw[i] = ph[i].tw; a.pbh[i] = ph[i].bh; a.pbw[i] = ph[i].bw;
+      a.pwp[i] = reinterpret_cast<const _Float16*>(pk + X3_HEADER_FLOATS);
+      pk += x3_phase_floats(ph[i], Ct, d->Cout);
+    }
+    a.wp = a.pwp[0];
+    a.yin = nullptr;
+    a.final = 1;
+    if (rs && !x1_range) a.xr1 = reinterpret_cast<const unsigned*>(prepared) + 2;
+    return launch_x3<false, 4, 4, true>(a, st);
+  }
   for (int i = 0; i < n; ++i) {
     a.hdr = pk;
     a.wp = reinterpret_cast<const _Float16*>(pk + X3_HEADER_FLOATS);
