@@ -89,7 +89,8 @@ def test_frontend_quad_switch_is_bit_identical(shdr, monkeypatch):
 @pytest.mark.parametrize("var,shape", [
     ("SHDR_NO_X3", (2, 48, 64, 64, 0, 128, 3, 1)), ("SHDR_NO_X3", (1, 40, 40, 64, 64, 64, 3, 1)), ("SHDR_NO_X3_1X1", (1, 40, 56, 256, 256, 128, 1, 1)),
     ("SHDR_NO_X3_STRIDE2", (1, 64, 80, 96, 0, 64, 7, 2)), ("SHDR_NO_X3N", (1, 40, 56, 16, 0, 16, 7, 1)), ("SHDR_NO_X3N", (1, 40, 56, 16, 16, 16, 3, 1)),
-    ("SHDR_NO_WINOGRAD", (1, 48, 48, 64, 0, 64, 3, 1))])
+    ("SHDR_NO_WINOGRAD", (1, 48, 48, 64, 0, 64, 3, 1)), ("SHDR_NO_X3_COUT32", (2, 40, 56, 64, 0, 32, 3, 1)),
+    ("SHDR_NO_X3_COUT32", (1, 40, 56, 32, 32, 32, 3, 1))])
 def test_split_operand_switches(shdr, monkeypatch, var, shape):
     """the split-operand fp16 kernels (plans "x3" / "x3n") against the exact-fp32 kernel the switch falls back to: both fp32-grade"""
     K = shdr._ops
@@ -104,6 +105,21 @@ def test_split_operand_switches(shdr, monkeypatch, var, shape):
     assert K.conv2d_plan((n, h, w, c1), tuple(wt.shape), c2=c2, stride=s) not in ("x3", "x3n")
     ref = K.conv2d(x, wt, b, stride=s, x2=x2, act1=K.ACT_RELU)
     assert maxrel(got, ref) <= 5e-6, (var, plan)
+
+
+def test_stem_phase_launches_switch(shdr, monkeypatch):
+    """the 7x7 / stride-2 stem in one launch (partial sums of the four parity phases in registers) vs four launches accumulating in y:
+    the same products in the same order within a phase, the phases summed in another order"""
+    K = shdr._ops
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    for n, h, w in ((1, 64, 80), (2, 70, 46)):               # (ragged tiles, odd output sizes in the second case)
+        x, wt, b = _rand(n, h, w, 96, seed=30), _rand(7, 7, 96, 64, seed=31, scale=1.0 / (7 * 96 ** 0.5)), _rand(64, seed=32)
+        assert K.conv2d_plan((n, h, w, 96), tuple(wt.shape), stride=2) == "x3"
+        one = K.conv2d(x, wt, b, stride=2, act1=K.ACT_RELU)
+        monkeypatch.setenv("SHDR_X3_STEM_PHASE_LAUNCHES", "1")
+        four = K.conv2d(x, wt, b, stride=2, act1=K.ACT_RELU)
+        monkeypatch.delenv("SHDR_X3_STEM_PHASE_LAUNCHES")
+        assert maxrel(one, four) <= 2e-6
 
 
 def test_x3_up_always_switch_is_bit_identical(shdr, monkeypatch):
