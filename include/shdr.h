@@ -459,6 +459,11 @@ int shdr_conv2d_fwd_x3_f32(const shdr_conv2d_desc* d, const float* x1, const flo
 int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                   const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
                                   const float* x2_range, float* y_range, void* stream);
+/* the same with a residual [N,Ho,Wo,res_cstride] added between the affine and act2 (stride-1 layers: the ResNet joins of
+ * linearization_net.py:6-48 on the 1x1 layers); reached through shdr_conv2d_fwd_prepared_f32 */
+int shdr_conv2d_fwd_x3_residual_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                    const float* scale, const float* shift, const float* residual, float* y, const float* x1_range,
+                                    const float* x2_range, float* y_range, void* stream);
 /* the same launch with a projected output (see shdr_conv2d_fwd_prepared_projected_f32); proj [3][64], Cout = 64 */
 int shdr_conv2d_fwd_x3_projected_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
                                      const float* scale, const float* shift, const float* proj, float* y_proj, float* y, float* y_pool,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "shdr_conv2d_projected_ok_f32": (c_int, [ctypes.POINTER(ConvDesc)]),
     "shdr_conv2d_fwd_prepared_projected_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 15),
     "shdr_conv2d_fwd_x3_projected_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 14),
+    "shdr_conv2d_fwd_x3_residual_f32": (c_int, [ctypes.POINTER(ConvDesc)] + [c_ptr] * 12),
     "shdr_conv2d_dgrad_workspace_bytes_f32": (c_i64, [ctypes.POINTER(ConvDesc), c_int]),
     "shdr_conv2d_dgrad_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "shdr_conv2d_dgrad_tracks_range_f32": (c_int, [ctypes.POINTER(ConvDesc), c_int]),

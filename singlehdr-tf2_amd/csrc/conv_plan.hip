@@ -41,7 +41,10 @@ int plan_of(const shdr_conv2d_desc* d, bool has_residual) {
   if (d->algo == SHDR_ALGO_AUTO && same && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3n_ok_f32(d)) return SHDR_PLAN_X3N;
   // the split-operand fp16 kernel first (1.4-1.5x the fused Winograd kernel's rate, same accuracy class; also the 7x7 / 2 stem);
   // SHDR_ALGO_AUTO_EXACT opts out
-  if (d->algo == SHDR_ALGO_AUTO && !has_residual && same && SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d)) return SHDR_PLAN_X3;
+  // (with a residual: the stride-1 layers only -- the ResNet joins on the 1x1 layers; shdr_conv2d_fwd_x3_residual_f32)
+  if (d->algo == SHDR_ALGO_AUTO && (!has_residual || (d->stride == 1 && d->res_cstride % 4 == 0 && SHDR_ENV("SHDR_NO_X3_RESIDUAL") == nullptr)) && same &&
+      SHDR_ENV("SHDR_NO_WINOGRAD") == nullptr && shdr_conv2d_x3_ok_f32(d))
+    return SHDR_PLAN_X3;
   if (wino_shape) {
     const bool two_ok = d->C2 == 0 || (d->C2 == d->C1 && d->C1 % 8 == 0 && d->x2_scale == 1.0f);
     if (two_ok && Ct % 8 == 0 && d->Cout % 64 == 0 && Ct >= 32 && (long)d->N * d->H * d->W * Ct < (1L << 32)) return SHDR_PLAN_WINOGRAD_FUSED;
@@ -297,7 +300,13 @@ extern "C" int shdr_conv2d_fwd_prepared_ranged_f32(const shdr_conv2d_desc* d, co
   if (plan == SHDR_PLAN_WINOGRAD_FUSED)
     return shdr_conv2d_winograd_fused2_f32(x1, x2, prepared, bias, scale, shift, y, y_pool, d->N, d->H, d->W, d->C1, d->C2, d->Cout, d->act1,
                                            d->act2, stream);
-  if (plan == SHDR_PLAN_X3) return shdr_conv2d_fwd_x3_ranged_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, x1_range, x2_range, y_range, stream);
+  if (plan == SHDR_PLAN_X3) {
+    if (residual) {
+      SHDR_REQUIRE(y && !y_pool, SHDR_E_SHAPE, "conv2d_fwd_prepared: a layer with a residual writes y and has no pooled output");
+      return shdr_conv2d_fwd_x3_residual_f32(d, x1, x2, prepared, bias, scale, shift, residual, y, x1_range, x2_range, y_range, stream);
+    }
+    return shdr_conv2d_fwd_x3_ranged_f32(d, x1, x2, prepared, bias, scale, shift, y, y_pool, x1_range, x2_range, y_range, stream);
+  }
   SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_fwd_prepared: y may be omitted only on the fused Winograd and split-operand paths");
   int rc;
   if (plan == SHDR_PLAN_X3N) {

@@ -70,6 +70,8 @@ struct X3Args {
   float* y;                // [N,H,W,Cout] (or null when only the pooled tensor is wanted)
   float* yp;               // [N,H/2,W/2,Cout] = MaxPool2D(2)(y), or null
   const float* yin;        // partial sums of earlier phases to add (same layout as y), or null
+  const float* res;        // residual added between the affine and act2 (the ResNet joins of linearization_net.py:6-48), or null
+  int res_cs;              // its channels per pixel
   int N, H, W, C1, C2, Cout, tiles_x, tiles_y, nblk_m, nblk_n, act1, act2;
   int Hl, Wl;              // UP: x1 is the low-res tensor [N,Hl,Wl,C1], H = 2 Hl, W = 2 Wl
   int Hin, Win;            // input tensor [N,Hin,Win,C]; tap (kh, kw) of output (oh, ow) reads input (in_s (oh + kh) + bh, in_s (ow + kw) + bw)
@@ -425,8 +427,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     shift_r[ni] = (a.scale && a.final && cv) ? *reinterpret_cast<const f32x4*>(a.shift + ep0 + cl) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // the partial sums of the earlier phases of a stride-2 layer (yin), batched in front of the stores for the same reason
+  // (the residual of a final launch travels in the same registers: a layer has partial sums OR a residual)
   f32x4 yin_r[MT / 2][NT][2];
-  if (a.yin) {
+  const float* addend = a.yin ? a.yin : (a.final ? a.res : nullptr);
+  if (addend) {
+    const int add_cs = a.yin ? a.Cout : a.res_cs;
 #pragma unroll
     for (int mp = 0; mp < MT / 2; ++mp)
 #pragma unroll
@@ -434,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int oh = oh0 + wave * MT + 2 * mp + r;
-          yin_r[mp][ni][r] = (oh < a.H && ow < a.W)
-                                 ? *reinterpret_cast<const f32x4*>(a.yin + ((size_t)(img * a.H + oh) * a.W + ow) * a.Cout + ep0 + ni * 16 + 4 * fg)
+          yin_r[mp][ni][r] = (oh < a.H && ow < a.W && ep0 + ni * 16 + 4 * fg < a.Cout)
+                                 ? *reinterpret_cast<const f32x4*>(addend + ((size_t)(img * a.H + oh) * a.W + ow) * add_cs + ep0 + ni * 16 + 4 * fg)
                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
   }
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
         v[r] += bias_r[ni];
         shdr::act_apply4<false>(v[r], a.act1);
         if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
+        if (a.res) v[r] += yin_r[mp][ni][r];
         shdr::act_apply4<false>(v[r], a.act2);
         if (a.y && oh + r < a.H && ow < a.W && n0 + cl < a.Cout)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
@@ -580,8 +586,9 @@ struct X3Phase { int th, tw, p0, q0, step, bh, bw; };
 // meet the filter taps of one parity only, so the layer is the sum of four stride-1 correlations of the parity-subsampled input with
 // the 4 x 4, 4 x 3, 3 x 4 and 3 x 3 sub-filters -- exactly the 49 taps, each phase one launch accumulating into y.
 int x3_phases(const shdr_conv2d_desc* d, X3Phase ph[4]) {
-  if (d->stride == 1) {
-    ph[0] = X3Phase{d->KH, d->KW, 0, 0, 1, -d->pad_t, -d->pad_l};        // 3 x 3 (pad 1) or 1 x 1 (pad 0): all taps in one launch
+  if (d->stride == 1 || d->KH == 1) {
+    // 3 x 3 (pad 1) or 1 x 1 (pad 0): all taps in one launch; the 1 x 1 / stride-2 layer reads input pixel (2 oh, 2 ow)
+    ph[0] = X3Phase{d->KH, d->KW, 0, 0, d->stride, -d->pad_t, -d->pad_l};
     return 1;
   }
   int n = 0;
@@ -622,8 +629,15 @@ extern "C" int shdr_conv2d_x3_ok_f32(const shdr_conv2d_desc* d) {
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad_t == 1 && d->pad_l == 1;
     // 1 x 1 layers (the skip layers of hallucination_net.py:93-107 on tf.concat of two sources, the bottleneck convs of the ResNet
     // blocks): one tap per chunk, so the patch split is not amortised over nine taps -- still 2-3x the fp32-MFMA kernel from K = 256 on
-    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= 256 && SHDR_ENV("SHDR_NO_X3_1X1") == nullptr;
+    int k1_min = 64;                                           // (measured, tools/one_1x1.py: 64 -> 256 at 16 x 128^2 0.171 -> 0.129 ms, 128 -> 512 at 64^2 0.119 -> 0.073)
+    if (const char* e = SHDR_ENV("SHDR_X3_1X1_MIN_K")) k1_min = atoi(e);
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad_t == 0 && d->pad_l == 0 && d->C1 + d->C2 >= k1_min && SHDR_ENV("SHDR_NO_X3_1X1") == nullptr;
     if (!(k3 || k1) || d->Ho != d->H || d->Wo != d->W) return 0;
+  } else if (d->stride == 2 && d->KH == 1 && d->KW == 1) {
+    // the 1 x 1 / stride-2 projections of the ResNet blocks (linearization_net.py:6-48, res4): the 1 x 1 kernel on every other input pixel
+    if (d->pad_t != 0 || d->pad_l != 0 || d->C2 != 0 || d->prologue != SHDR_PROLOGUE_NONE || d->Ho != (d->H + 1) / 2 || d->Wo != (d->W + 1) / 2 ||
+        d->C1 < 64 || SHDR_ENV("SHDR_NO_X3_1X1") || SHDR_ENV("SHDR_NO_X3_STRIDE2"))
+      return 0;
   } else {
     // the 7 x 7 / stride-2 stem with TF SAME padding (one source, no prologue)
     int ho = 0, wo = 0, pt = 0, pl = 0;
@@ -708,8 +722,8 @@ extern "C" int shdr_conv2d_x3_input_absmax_f32(const float* x, int64_t n, float*
 }
 
 static int x3_forward(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
-                      const float* scale, const float* shift, float* y, float* y_pool, const float* proj, float* y_proj, const float* x1_range,
-                      const float* x2_range, float* y_range, void* stream) {
+                      const float* scale, const float* shift, const float* residual, float* y, float* y_pool, const float* proj, float* y_proj,
+                      const float* x1_range, const float* x2_range, float* y_range, void* stream) {
   SHDR_REQUIRE(d && x1 && prepared && (y || y_pool || y_proj), SHDR_E_NULL, "conv2d_x3: null desc/x1/filter or no output");
   SHDR_REQUIRE((proj == nullptr) == (y_proj == nullptr), SHDR_E_NULL, "conv2d_x3: proj and y_proj come together");
   SHDR_REQUIRE(!proj || (d->Cout == 64 && d->stride == 1 && shdr::aligned16(proj)), SHDR_E_SHAPE,
@@ -741,6 +755,9 @@ static int x3_forward(const shdr_conv2d_desc* d, const float* x1, const float* x
   a.xr2 = reinterpret_cast<const unsigned*>(x2 ? x2_range : nullptr);
   a.yr = reinterpret_cast<unsigned*>(y_range);
   a.proj = proj; a.yproj = y_proj;
+  SHDR_REQUIRE(!residual || (d->stride == 1 && d->res_cstride >= d->Cout && d->res_cstride % 4 == 0 && shdr::aligned16(residual) && !y_pool && !proj), SHDR_E_SHAPE,
+               "conv2d_x3: the residual takes a stride-1 layer, res_cstride >= Cout (a multiple of 4), a 16-byte aligned tensor, no pooled / projected output");
+  a.res = residual; a.res_cs = d->res_cstride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   X3Phase ph[4];
   const int n = x3_phases(d, ph);
@@ -789,7 +806,16 @@ extern "C" int shdr_conv2d_fwd_x3_ranged_f32(const shdr_conv2d_desc* d, const fl
                                              const float* scale, const float* shift, float* y, float* y_pool, const float* x1_range,
                                              const float* x2_range, float* y_range, void* stream) {
   SHDR_REQUIRE(y || y_pool, SHDR_E_NULL, "conv2d_x3: neither y nor y_pool");
-  return x3_forward(d, x1, x2, prepared, bias, scale, shift, y, y_pool, nullptr, nullptr, x1_range, x2_range, y_range, stream);
+  return x3_forward(d, x1, x2, prepared, bias, scale, shift, nullptr, y, y_pool, nullptr, nullptr, x1_range, x2_range, y_range, stream);
+}
+
+// The same with a residual: y = act2(affine(act1(conv + bias)) + residual), residual [N,Ho,Wo,res_cstride] -- the joins of the ResNet
+// blocks (linearization_net.py:6-48: relu(norm(conv) + shortcut)) on the 1x1 layers this kernel takes
+extern "C" int shdr_conv2d_fwd_x3_residual_f32(const shdr_conv2d_desc* d, const float* x1, const float* x2, const float* prepared, const float* bias,
+                                               const float* scale, const float* shift, const float* residual, float* y, const float* x1_range,
+                                               const float* x2_range, float* y_range, void* stream) {
+  SHDR_REQUIRE(y, SHDR_E_NULL, "conv2d_x3: null y");
+  return x3_forward(d, x1, x2, prepared, bias, scale, shift, residual, y, nullptr, nullptr, nullptr, x1_range, x2_range, y_range, stream);
 }
 
 // The same launch with a PROJECTED output: y_proj[n,h,w,j] = sum_c proj[j][c] * y[n,h,w,c] (proj: [3][64] floats, j < 3), written from
@@ -802,7 +828,7 @@ extern "C" int shdr_conv2d_fwd_x3_projected_f32(const shdr_conv2d_desc* d, const
                                                 float* y, float* y_pool, const float* x1_range, const float* x2_range, float* y_range,
                                                 void* stream) {
   SHDR_REQUIRE(proj && y_proj, SHDR_E_NULL, "conv2d_x3_projected: null proj / y_proj");
-  return x3_forward(d, x1, x2, prepared, bias, scale, shift, y, y_pool, proj, y_proj, x1_range, x2_range, y_range, stream);
+  return x3_forward(d, x1, x2, prepared, bias, scale, shift, nullptr, y, y_pool, proj, y_proj, x1_range, x2_range, y_range, stream);
 }
 
 // The low-level entry point without range slots: the input is split as it stands (|x| must stay inside the fp16 range) unless

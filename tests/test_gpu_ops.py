@@ -494,9 +494,10 @@ def test_split_operand_range_slots_travel_with_the_tensors(shdr, monkeypatch):
         c = K.clip(y2, 0.0, 1.0)
         assert c._shdr_bound == 1.0 and float(K._range_of(c)) == 1.0
         # the exact-fp32 MFMA / direct kernels track their output range too (their consumer may be a split-operand layer)
-        w3 = dev(f32(rng.normal(size=(1, 1, 64, 64)) / 8)).requires_grad_(True)
+        w3 = dev(f32(rng.normal(size=(1, 1, 64, 96)) / 8)).requires_grad_(True)       # (96 couts: not a split-operand layer)
         assert K.conv2d_plan(tuple(y2.shape), tuple(w3.shape)) == "mfma"
-        for kw in (dict(), dict(act1=K.ACT_RELU, residual=y2, act2=K.ACT_RELU)):
+        res96 = dev(f32(rng.normal(size=tuple(y2.shape[:3]) + (96,))))
+        for kw in (dict(), dict(act1=K.ACT_RELU, residual=res96, act2=K.ACT_RELU)):
             y3 = K.conv2d(y2, w3, **kw)
             assert float(y3._shdr_range) == float(y3.abs().max())
         w4 = dev(f32(rng.normal(size=(1, 1, 64, 3)))).requires_grad_(True)
@@ -694,6 +695,45 @@ def test_conv2d_x3_thirty_two_couts(shdr, monkeypatch):
     assert rel_err(host(dx), oracle_conv(dz, np.ascontiguousarray(wf[::-1, ::-1].transpose(0, 1, 3, 2)))) <= TOL
 
 
+def test_conv2d_x3_residual_joins(shdr, monkeypatch):
+    """the ResNet joins of the Linearization-Net (linearization_net.py:6-48: relu(norm(conv1x1) + shortcut)) on the split-operand kernel:
+    folded BatchNorm, residual added between the affine and the relu; 64 -> 256, 128 -> 512 and a 3x3 layer with a wider residual tensor"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    K = shdr._ops
+    rng = np.random.default_rng(31)
+    for (n, h, w, cin, cout, k, res_c) in ((2, 40, 56, 64, 256, 1, 256), (1, 24, 40, 128, 512, 1, 512), (1, 22, 38, 64, 64, 3, 128)):
+        x = f32(rng.normal(size=(n, h, w, cin)))
+        wt = f32(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+        sc, sh = f32(rng.uniform(0.5, 1.5, size=cout)), f32(rng.normal(size=cout))
+        res = f32(rng.normal(size=(n, h, w, res_c)))
+        assert K.conv2d_plan((n, h, w, cin), wt.shape, has_residual=True) == "x3"
+        y = K.conv2d(dev(x), dev(wt), None, scale=dev(sc), shift=dev(sh), residual=dev(res), act2=K.ACT_RELU)
+        ref = np.maximum(oracle_conv(x, wt) * sc + sh + res[..., :cout], 0.0)
+        assert rel_err(host(y), ref) <= TOL and float(y._shdr_range) == float(y.abs().max())
+        monkeypatch.setenv("SHDR_NO_X3_RESIDUAL", "1")
+        assert K.conv2d_plan((n, h, w, cin), wt.shape, has_residual=True) != "x3"
+        y_exact = K.conv2d(dev(x), dev(wt), None, scale=dev(sc), shift=dev(sh), residual=dev(res), act2=K.ACT_RELU)
+        monkeypatch.delenv("SHDR_NO_X3_RESIDUAL")
+        assert float((y - y_exact).abs().max()) <= 1e-5 * float(y_exact.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 56, 256, 512), (1, 33, 47, 256, 128), (1, 18, 22, 64, 64)])
+def test_conv2d_x3_1x1_stride2_projections(shdr, shape, monkeypatch):
+    """the 1x1 / stride-2 projections of the ResNet blocks (linearization_net.py:6-48, res4) on the split-operand kernel: the 1x1 kernel on
+    every other input pixel (TF SAME: no padding, ceil(H / 2) outputs); even and odd sizes, folded BatchNorm, vs the float64 oracle"""
+    monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    K = shdr._ops
+    x = f32(rng.normal(size=(n, h, w, cin)))
+    wt = f32(rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin))
+    sc, sh = f32(rng.uniform(0.5, 1.5, cout)), f32(rng.normal(size=cout))
+    assert K.conv2d_plan((n, h, w, cin), wt.shape, stride=2) == "x3"
+    y = K.conv2d(dev(x), dev(wt), None, stride=2, scale=dev(sc), shift=dev(sh), act2=K.ACT_RELU)
+    ref = oracle_conv(x, wt, None, stride=2, scale=sc, shift=sh, act2=1)
+    assert tuple(y.shape) == ref.shape == (n, (h + 1) // 2, (w + 1) // 2, cout) and rel_err(host(y), ref) <= TOL
+
+
 X3N_CASES = [  # name, n, h, w, c1, c2, cout (filter width), cout_valid, k, act1, residual
     ("deq_conv1_7x7_4_16", 1, 40, 52, 4, 0, 16, 16, 7, 2, False), ("deq_conv2_7x7_16_16", 2, 33, 47, 16, 0, 16, 16, 7, 2, False),
     ("deq_d2_5x5_16_32", 1, 24, 40, 16, 0, 32, 32, 5, 2, False), ("deq_u1_3x3_32_16", 1, 50, 34, 32, 0, 16, 16, 3, 2, False),
@@ -755,7 +795,7 @@ def test_conv2d_x3n_input_gradient(shdr, case, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128)])
 def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
-    """1x1 layers with K >= 256 on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet
+    """1x1 layers (K >= 64) on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet
     bottleneck convs): one tap per chunk; vs the float64 oracle at the exact-fp32 bar, ragged tiles"""
     monkeypatch.setenv("SHDR_X3_MIN_BLOCKS", "1")
     n, h, w, c1, c2, cout = shape
@@ -771,8 +811,12 @@ def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
     y = K.conv2d(dev(x), dev(wt), dev(b), x2=None if x2 is None else dev(x2), x2_scale=x2s, act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh),
                  act2=K.ACT_RELU)
     assert tuple(y.shape) == ref.shape and rel_err(host(y), ref) <= TOL
-    # with a fused residual the layer stays on the exact-fp32 kernel (the split kernel's epilogue has none)
-    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=x2s, has_residual=True) == "mfma"
+    # with a fused residual too (test_conv2d_x3_residual_joins)
+    res = f32(rng.normal(size=(n, h, w, cout)))
+    assert K.conv2d_plan((n, h, w, c1), wt.shape, c2=c2, x2_scale=x2s, has_residual=True) == "x3"
+    yr = K.conv2d(dev(x), dev(wt), dev(b), x2=None if x2 is None else dev(x2), x2_scale=x2s, act1=K.ACT_RELU, scale=dev(sc), shift=dev(sh),
+                  residual=dev(res), act2=K.ACT_RELU)
+    assert rel_err(host(yr), oracle_conv(x, wt, b, x2=x2, x2_scale=x2s, act1=1, scale=sc, shift=sh, residual=res, act2=1)) <= TOL
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96, 96, 64), (1, 61, 75, 96, 64), (1, 32, 34, 32, 128), (1, 17, 16, 64, 64)])
