@@ -191,7 +191,8 @@ class model(Layer):
             return None
         wc, bc = self._tail_filter(c_skip)
         sc, sh = self.norm2.folded()
-        key = (self._tail[0], id(sc), id(sh))
+        n2 = self.norm2
+        key = (self._tail[0], n2.gamma._version, n2.beta._version, n2.moving_mean._version, n2.moving_variance._version)
         if getattr(self, "_tail_proj", None) is None or self._tail_proj[0] != key:
             with torch.no_grad():
                 m = wc[0, 0, :, :3] * sc[:3]                                   # [128, 3]
