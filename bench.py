@@ -458,6 +458,13 @@ def main():
             orig = K.conv2d
             depth = [0]
 
+            def x3_name(k, up=False):
+                # the instantiation's name as rocprofv3 prints it (profiles/*_kernel_stats.csv): <UP, KH, KW, MP>; the 7x7 / 2 stem is the
+                # phase-loop kernel on the 4 x 4 geometry
+                if k == 7:
+                    return "conv_x3_kernel<false, 4, 4, true>"
+                return "conv_x3_kernel<%s, %d, %d, false>" % ("true" if up else "false", k, k)
+
             def timed_conv(x, w, bias=None, stride=1, x2=None, **kw):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 wino = None
@@ -477,7 +484,7 @@ def main():
                     depth[0] -= 1
                 e1.record()
                 label = ("winograd_f2x2_3x3 (transforms + batched GEMM)" if wino == "planes" else
-                         "winograd_fused_kernel" if wino == "fused" else "conv_x3_kernel" if wino == "x3" else
+                         "winograd_fused_kernel" if wino == "fused" else x3_name(w.shape[0]) if wino == "x3" else
                          "conv_x3n_kernel" if wino == "x3n" else conv_variant(w, x, x2, kw.get("algo", 0), stride))
                 records.append((label, conv_flops(x, w, stride, kw.get("cout_valid")), e0, e1,
                                 "%dx%d %d+%d->%d k%d s%d" % (x.shape[1], x.shape[2], x.shape[3],
@@ -502,7 +509,7 @@ def main():
                 e1.record()
                 if out is None:                            # projection refused by the library: nothing was launched
                     return None
-                records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", conv_flops(x, w, 1, None), e0, e1,
+                records.append(("winograd_fused_kernel" if plan == "fused" else x3_name(3), conv_flops(x, w, 1, None), e0, e1,
                                 "%dx%d %d+0->%d k3 s1 +pool%s" % (x.shape[1], x.shape[2], x.shape[3], w.shape[3], " +proj" if proj is not None else ""), False))
                 return out
 
@@ -520,7 +527,7 @@ def main():
                 e0.record()
                 out = orig_ap(x, w, bias, act1, x2)
                 e1.record()
-                records.append(("conv_x3_kernel" if plan == "x3" else "conv_x3n_kernel", conv_flops(x, w, 1, None), e0, e1,
+                records.append((x3_name(w.shape[0]) if plan == "x3" else "conv_x3n_kernel", conv_flops(x, w, 1, None), e0, e1,
                                 "%dx%d %d+%d->%d k%d s1 +avgpool" % (x.shape[1], x.shape[2], x.shape[3], c2, w.shape[3], w.shape[0]), False))
                 return out
 
@@ -542,7 +549,7 @@ def main():
                 e1.record()
                 if out is None:
                     return None
-                records.append(("winograd_fused_kernel" if plan == "fused" else "conv_x3_kernel", 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
+                records.append(("winograd_fused_kernel" if plan == "fused" else x3_name(3, True), 2.0 * n * 4 * h * wd * c * w.shape[3] * 9, e0, e1,
                                 "%dx%d(x2) %d+0->%d k3 s1 +bilinear" % (h, wd, c, w.shape[3]), False))
                 return out
 
@@ -572,7 +579,8 @@ def main():
             # layers: top-level calls with the reference layer's algorithmic FLOPs; kernels: every launch of a conv
             # kernel (top-level direct convs + the GEMMs nested in Winograd layers, with the FLOPs they execute)
             layers, agg = {}, {}
-            for var, fl, sec, _, nested in calls:
+            is_x3 = lambda k: k.startswith("conv_x3")      # noqa: E731  (conv_x3_kernel<...> instantiations and conv_x3n_kernel)
+            for var, fl, sec, desc, nested in calls:
                 if not nested:
                     a = layers.setdefault(var, [0.0, 0.0, 0])
                     a[0] += fl; a[1] += sec; a[2] += 1
@@ -580,7 +588,9 @@ def main():
                     a = agg.setdefault(var, [0.0, 0.0, 0])
                     # per KERNEL the MFMA FLOPs it executes: the fused Winograd kernel runs 16 / 36 of the layer's direct-form FLOPs,
                     # the split-operand kernel three fp16 MFMA products per fp32 product
-                    a[0] += fl / 2.25 if var == "winograd_fused_kernel" else 3.0 * fl if var in ("conv_x3_kernel", "conv_x3n_kernel") else fl
+                    # (a 32-cout layer on conv_x3 runs a 64-cout slice: twice its own FLOPs)
+                    half = 2.0 if var.startswith("conv_x3_kernel") and "->32 k" in desc else 1.0
+                    a[0] += fl / 2.25 if var == "winograd_fused_kernel" else 3.0 * half * fl if is_x3(var) else fl
                     a[1] += sec; a[2] += 1
             reps = 1             # `calls` holds one pass
             dom = max(agg, key=lambda k: agg[k][1])
@@ -603,20 +613,19 @@ def main():
                 traffic = int(sum(b * n for b, n in hits) / sum(n for _, n in hits)) if hits else None
             except (OSError, KeyError, ValueError):
                 pass
-            X3K = ("conv_x3_kernel", "conv_x3n_kernel")
-            peak_of = lambda k: F16_MFMA_PEAK_TFLOPS if k in X3K else F32_MFMA_PEAK_TFLOPS      # noqa: E731
-            to_alg = {"winograd_fused_kernel": 2.25, "conv_x3_kernel": 1.0 / 3.0, "conv_x3n_kernel": 1.0 / 3.0}.get(dom, 1.0)
+            peak_of = lambda k: F16_MFMA_PEAK_TFLOPS if is_x3(k) else F32_MFMA_PEAK_TFLOPS      # noqa: E731
+            to_alg = 2.25 if dom == "winograd_fused_kernel" else 1.0 / 3.0 if is_x3(dom) else 1.0
             # time the matrix pipes need for one step at their peaks (fp32-MFMA kernels against 157.3, the fp16 split kernel against 2500)
             floor_ms = sum(a[0] / (peak_of(k) * 1e12) for k, a in agg.items()) * 1e3
             result["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak_of(dom),
                 "unit": "TFLOP/s", "frac": round(achieved / peak_of(dom), 4),
-                "mfma_dtype": "f16 (v_mfma_f32_16x16x32_f16, three products per fp32 product)" if dom in X3K else "f32 (v_mfma_f32_16x16x4_f32)",
+                "mfma_dtype": "f16 (v_mfma_f32_16x16x32_f16, three products per fp32 product)" if is_x3(dom) else "f32 (v_mfma_f32_16x16x4_f32)",
                 # SURVEY.md section 8(d) convention: the reference layers' direct-form fp32 FLOPs against the fp32-MFMA peak, no discount
                 # for what Winograd saves and no surcharge for the three fp16 products of the split kernel
                 "frac_algorithmic": round(achieved * to_alg / F32_MFMA_PEAK_TFLOPS, 4),
-                "whole_step": {"executed_gflop_f32_mfma": round(sum(a[0] for k, a in agg.items() if k not in X3K) / 1e9, 1),
-                               "executed_gflop_f16_mfma": round(sum(a[0] for k, a in agg.items() if k in X3K) / 1e9, 1),
+                "whole_step": {"executed_gflop_f32_mfma": round(sum(a[0] for k, a in agg.items() if not is_x3(k)) / 1e9, 1),
+                               "executed_gflop_f16_mfma": round(sum(a[0] for k, a in agg.items() if is_x3(k)) / 1e9, 1),
                                "mfma_floor_ms": round(floor_ms, 3),
                                "frac_executed": round(floor_ms / ms_per_step, 4),
                                "frac_algorithmic": round(conv_total_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
