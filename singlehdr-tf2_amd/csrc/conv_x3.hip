@@ -33,6 +33,8 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "shdr_internal.h"
 
 namespace {
@@ -217,7 +219,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
   }
   const int nch1 = a.C1 >> 5, nch = (a.C1 + a.C2) >> 5;
   int nunits = nch * NTAPS;                                    // (MP: per phase)
-  f32x4 pr[PJ];
+  // 1 x 1 layers run ONE tap (48 MFMAs, ~0.4 us) per chunk: a patch load issued one chunk ahead still has most of its HBM latency in
+  // front of it when the chunk is needed -- they prefetch TWO chunks ahead into two register sets (the chunk loop below alternates them)
+  constexpr int DEPTH = (NTAPS == 1 && !UP && !MP) ? 2 : 1;
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, DEPTH - 1>;
+  f32x4 pr_sets[DEPTH][PJ];
+#define pr (pr_sets[0])                                        /* the UP paths and the single-set kernels */
   auto load_lr = [&](int c) __attribute__((always_inline)) {                                  // UP: low-res chunk c -> the first LRJ registers
 #pragma unroll
     for (int j = 0; j < LRJ; ++j) {
@@ -273,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       if (j & 1) __builtin_amdgcn_sched_barrier(0);            // two pieces (32 registers of taps) in flight, not eleven: no spills
     }
   };
-  auto load_patch = [&](int c) __attribute__((always_inline)) {                               // chunk c -> registers
+  auto load_patch = [&](int c, auto setc) __attribute__((always_inline)) {                    // chunk c -> register set setc
+    constexpr int S = decltype(setc)::value;
     if (UP) { load_lr(c); return; }
     const bool second = c >= nch1;
     const float* src = second ? a.x2 : a.x1;
@@ -282,15 +291,16 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
       const int q = (tid + 256 * j) & 7;
-      pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ppix[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)ppix[j] * (unsigned)Cs + c0 + 4 * q);
+      pr_sets[S][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ppix[j] >= 0) pr_sets[S][j] = *reinterpret_cast<const f32x4*>(src + (size_t)(unsigned)ppix[j] * (unsigned)Cs + c0 + 4 * q);
     }
   };
-  auto store_patch = [&]() __attribute__((always_inline)) {                                   // registers -> the two fp16 images
+  auto store_patch = [&](auto setc) __attribute__((always_inline)) {                          // register set setc -> the two fp16 images
+    constexpr int S = decltype(setc)::value;
     if (UP) { expand_store(); return; }
 #pragma unroll
     for (int j = 0; j < PJ; ++j)
-      if (pdst[j] >= 0) split_store(pdst[j], pr[j]);
+      if (pdst[j] >= 0) split_store(pdst[j], pr_sets[S][j]);
   };
   // ---- filter units: 8 KB per tap = 512 pieces of 16 bytes, two per thread --------------------------------------------------------
   constexpr int FJ = 2;
@@ -341,18 +351,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
     patch_geometry(a.pbh[phase], a.pbw[phase]);
     if (phase > 0) __syncthreads();                            // every wave has read the last tap of the previous phase (patch and filter buffers)
   }
-  load_patch(0);
+  load_patch(0, Set0{});
+  if (DEPTH == 2 && nch > 1) load_patch(1, Set1{});
   load_filt(0);
   if (!MP || phase == 0) x3_range_scale(a.xr1, a.xr2, xs, ixs);
   if (UP) {
     park_lr();
     __syncthreads();
   }
-  store_patch();
+  store_patch(Set0{});
   store_filt(0);
-#pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) load_patch(c + 1);                        // lands under the taps of this chunk
+  // one chunk: `cur` = the register set chunk c was loaded into (already split into LDS: free for chunk c + DEPTH), `nxt` = the set of chunk c + 1
+  auto chunk = [&](int c, auto cur, auto nxt) __attribute__((always_inline)) {
+    if (c + DEPTH < nch) load_patch(c + DEPTH, cur);           // lands under the taps of this chunk (and, for the 1 x 1 layers, of the next)
 #pragma unroll 1
     for (int kh = 0; kh < (MP ? kh_n : KH); ++kh) {
 #pragma unroll
@@ -400,10 +411,16 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
       } else {
         __syncthreads();                                       // every wave has read the last tap of this chunk's patch
       }
-      store_patch();                                           // visible after the barrier at the top of the next tap loop
+      store_patch(nxt);                                        // visible after the barrier at the top of the next tap loop
     }
+  };
+#pragma unroll 1
+  for (int c = 0; c < nch; c += DEPTH) {
+    chunk(c, Set0{}, Set1{});
+    if (DEPTH == 2 && c + 1 < nch) chunk(c + 1, Set1{}, Set0{});
   }
   }                                                            // phase loop
+#undef pr
 
   // ---- epilogue: y = act2(affine(act1(acc * 2^-S + bias))), 16-byte stores (lane = pixel x 4 consecutive couts); the 2 x 2 pooling
   //      window of the optional second output is two rows of this lane and of its neighbour lane -----------------------------------
