@@ -91,6 +91,8 @@ __device__ __forceinline__ void xn_range_out(unsigned* slot, float m, int lane, 
   }
 }
 
+struct __attribute__((packed, aligned(4))) f32x3u { float x, y, z; };      // 12 bytes at 4-byte alignment: global_load / store_dwordx3
+
 __host__ __device__ inline int pswz(int row) { return (-(row >> 2)) & 3; }
 
 template <int KK, int CT, int NT, bool TWO>
@@ -360,19 +362,31 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
             if (a.bias && co + e < a.cout_valid) t[e] = a.bias[co + e];
           v += t;
           shdr::act_apply4<TANH>(v, a.act1);
+          const bool three = a.cout_valid == 3;                     // the 3-channel heads: ONE 12-byte access per pixel instead of three scalar ones
+          if (three && a.res) {                                     // (16 lanes x 12 bytes are contiguous: a pixel row of the image)
+            const f32x3u r3 = *reinterpret_cast<const f32x3u*>(a.res + pix * a.res_cs);
+            t = (f32x4){r3.x, r3.y, r3.z, 0.f};
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (co + e < a.cout_valid) {
               if (a.scale) v[e] = v[e] * a.scale[co + e] + a.shift[co + e];
-              if (a.res) v[e] += a.res[pix * a.res_cs + co + e];
+              if (a.res) v[e] += three ? t[e] : a.res[pix * a.res_cs + co + e];
             }
           shdr::act_apply4<TANH>(v, a.act2);
+          if (three) {
+            f32x3u o3;
+            o3.x = v[0]; o3.y = v[1]; o3.z = v[2];
+            *reinterpret_cast<f32x3u*>(a.y + pix * 3) = o3;
+            if (a.yr) ym = fmaxf(fmaxf(fmaxf(ym, fabsf(v[0])), fabsf(v[1])), fabsf(v[2]));
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < a.cout_valid) {
-              a.y[pix * a.cout_valid + co + e] = v[e];
-              if (a.yr) ym = fmaxf(ym, fabsf(v[e]));
-            }
+            for (int e = 0; e < 4; ++e)
+              if (co + e < a.cout_valid) {
+                a.y[pix * a.cout_valid + co + e] = v[e];
+                if (a.yr) ym = fmaxf(ym, fabsf(v[e]));
+              }
+          }
         }
       }
     }
