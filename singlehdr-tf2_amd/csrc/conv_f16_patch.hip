@@ -214,13 +214,13 @@ __global__ __launch_bounds__(256) void conv_f16_patch_kernel(const PatchArgs a) 
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (a.bias && co + e < a.cout_valid) v[e] += a.bias[co + e];
-          shdr::act_apply4<true>(v, a.act1);
+          shdr::act_apply4<1>(v, a.act1);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (co + e < a.cout_valid) a.y32[pix * a.cout_valid + co + e] = v[e];
         } else {
           v += bias_r[ni];
-          shdr::act_apply4<false>(v, a.act1);                    // (fp16 outputs with tanh go to the general kernel: shdr_conv2d_fwd_f16)
+          shdr::act_apply4<0>(v, a.act1);                    // (fp16 outputs with tanh go to the general kernel: shdr_conv2d_fwd_f16)
           f16x4 h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_w3_kernel(const W3Args a) {
         const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + cl);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
       }
-      shdr::act_apply4<false>(v, a.act1);                      // (no tanh here: shdr_conv2d_w3_ok_f16; shdr_internal.h act_apply4)
+      shdr::act_apply4<0>(v, a.act1);                      // (no tanh here: shdr_conv2d_w3_ok_f16; shdr_internal.h act_apply4)
       f16x4 h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];

@@ -481,10 +481,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const X3Args a) {
           continue;
         }
         v[r] += bias_r[ni];
-        shdr::act_apply4<false>(v[r], a.act1);
+        shdr::act_apply4<0>(v[r], a.act1);
         if (a.scale) v[r] = v[r] * scale_r[ni] + shift_r[ni];
         if (a.res) v[r] += yin_r[mp][ni][r];
-        shdr::act_apply4<false>(v[r], a.act2);
+        shdr::act_apply4<0>(v[r], a.act2);
         if (a.y && oh + r < a.H && ow < a.W && n0 + cl < a.Cout)
           *reinterpret_cast<f32x4*>(a.y + ((size_t)(img * a.H + oh + r) * a.W + ow) * a.Cout + n0 + cl) = v[r];
         if (a.proj) {

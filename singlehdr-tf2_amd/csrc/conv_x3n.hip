@@ -113,8 +113,10 @@ struct NG {
 };
 
 // TANH: the epilogue knows SHDR_ACT_TANH (instantiated for the 16-cout single-source layers only: shdr_conv2d_x3n_ok_f32)
+// (the 3x3 tanh heads are held to three waves per SIMD like their tanh-free twins: with libm's tanhf the instantiation took 9 registers more
+//  and lost a third of its occupancy -- 0.205 vs 0.159 ms for the 16 -> 3 head, none of it the tanh arithmetic itself)
 template <int KK, int CT, int NT, bool TWO, bool TANH>
-__global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
+__global__ __launch_bounds__(256, (TANH && KK == 3 && CT <= 16) ? 3 : 1) void conv_x3n_kernel(const X3nArgs a) {
   using G = NG<KK, CT, NT, TWO>;
   constexpr int MT = 4;                                        // wave w owns tile rows 4w .. 4w+3
   constexpr int PAD = (KK - 1) / 2;
@@ -341,13 +343,13 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
         // y = act2(affine(act1(acc + bias)) + residual)
         if (a.cout_valid == G::COUT) {
           v += bias_r[ni];
-          shdr::act_apply4<TANH>(v, a.act1);
+          shdr::act_apply4<(TANH ? 2 : 0)>(v, a.act1);
           if (a.scale) v = v * *reinterpret_cast<const f32x4*>(a.scale + co) + *reinterpret_cast<const f32x4*>(a.shift + co);
           if (a.res) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += a.res[pix * a.res_cs + co + e];
           }
-          shdr::act_apply4<TANH>(v, a.act2);
+          shdr::act_apply4<(TANH ? 2 : 0)>(v, a.act2);
           // 16 lanes x 16 bytes at a stride of COUT * 4 bytes: the four lane groups of a pixel complete its 64- / 128-byte row
           *reinterpret_cast<f32x4*>(a.y + pix * G::COUT + co) = v;
 #ifndef SHDR_ABL_NO_YM
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
           for (int e = 0; e < 4; ++e)
             if (a.bias && co + e < a.cout_valid) t[e] = a.bias[co + e];
           v += t;
-          shdr::act_apply4<TANH>(v, a.act1);
+          shdr::act_apply4<(TANH ? 2 : 0)>(v, a.act1);
           const bool three = a.cout_valid == 3;                     // the 3-channel heads: ONE 12-byte access per pixel instead of three scalar ones
           if (three && a.res) {                                     // (16 lanes x 12 bytes are contiguous: a pixel row of the image)
             const f32x3u r3 = *reinterpret_cast<const f32x3u*>(a.res + pix * a.res_cs);
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const X3nArgs a) {
               if (a.scale) v[e] = v[e] * a.scale[co + e] + a.shift[co + e];
               if (a.res) v[e] += three ? t[e] : a.res[pix * a.res_cs + co + e];
             }
-          shdr::act_apply4<TANH>(v, a.act2);
+          shdr::act_apply4<(TANH ? 2 : 0)>(v, a.act2);
           if (three) {
             f32x3u o3;
             o3.x = v[0]; o3.y = v[1]; o3.z = v[2];

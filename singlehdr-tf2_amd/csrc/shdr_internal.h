@@ -151,7 +151,20 @@ __device__ __forceinline__ void range_out_block256(unsigned* slot, float m) {
 // routine of ~45 instructions -- only in kernels instantiated with TANH.  The epilogues of the convolution kernels apply two
 // activations to 64 accumulators per lane: with act_apply() per element the epilogue alone was 40 - 70 KB of code (256 copies of
 // tanhf), more than the 64 KB instruction cache, and it sits inside the tile loop of the persistent kernels.
-template <bool TANH, class V4>
+// tanh for the heads of the fp32 split-operand kernel: 1 - 2 / (e^{2|x|} + 1) with the hardware exponential and reciprocal (relative error
+// < 1e-6 for |x| >= 0.1), the odd polynomial x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315) below it (truncation 1.4e-9 at 0.1) -- the accuracy
+// class of the split-operand products themselves (3 * 2^-22 each).  Few registers: the libm routine cost the 16 -> 3 head kernel a wave
+// per SIMD (conv_x3n.hip: launch bounds of the 3x3 tanh instantiations; tools/head_cost.py)
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float e = __expf(2.0f * ax);                          // inf for large |x|: 2 / inf = 0 -> 1
+  const float big = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+  const float small = ax * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
+  return copysignf(ax < 0.1f ? small : big, x);
+}
+
+// TANH: 0 = not compiled in, 1 = libm's tanhf, 2 = tanh_fast
+template <int TANH, class V4>
 __device__ __forceinline__ void act_apply4(V4& v, int act) {
   switch (act) {
     case SHDR_ACT_RELU:
@@ -163,9 +176,9 @@ __device__ __forceinline__ void act_apply4(V4& v, int act) {
       for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * 0.1f;
       break;
     case SHDR_ACT_TANH:
-      if constexpr (TANH) {
+      if constexpr (TANH != 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = TANH == 2 ? tanh_fast(v[e]) : tanhf(v[e]);
       }
       break;
     default:
