@@ -113,10 +113,20 @@ struct NG {
 };
 
 // TANH: the epilogue knows SHDR_ACT_TANH (instantiated for the 16-cout single-source layers only: shdr_conv2d_x3n_ok_f32)
-// (the 3x3 tanh heads are held to three waves per SIMD like their tanh-free twins: with libm's tanhf the instantiation took 9 registers more
-//  and lost a third of its occupancy -- 0.205 vs 0.159 ms for the 16 -> 3 head, none of it the tanh arithmetic itself)
+// Waves per SIMD the register allocator is held to (rocm 7.2 spends registers freely when nothing bounds it: the 4 -> 64 image layer
+// <3,8,4> sat at 168 + 96 accumulation registers = one wave per SIMD for a kernel that fits 215, 0.386 -> 0.277 ms; the 3x3 tanh heads took
+// 9 registers more than their tanh-free twins and lost their third wave, 0.252 -> 0.203 ms): 3 for the 3x3 tanh heads, 2 wherever the
+// instantiation fits 256 registers without spilling (every 3x3 form, the 4(8)-channel image layers, 5x5 16 -> 16), unbounded for the
+// wide 5x5 / 7x7 forms, which would spill 30 - 400 registers (measured 2 - 4x slower)
+template <int KK, int CT, int NT>
+constexpr int x3n_min_waves(bool tanh_head) {
+#ifdef SHDR_ABL_X3N_NO_BOUNDS
+  return 1;
+#endif
+  return (tanh_head && KK == 3 && CT <= 16) ? 3 : (KK == 3 || CT == 8 || (KK == 5 && CT == 16 && NT == 1)) ? 2 : 1;
+}
 template <int KK, int CT, int NT, bool TWO, bool TANH>
-__global__ __launch_bounds__(256, (TANH && KK == 3 && CT <= 16) ? 3 : 1) void conv_x3n_kernel(const X3nArgs a) {
+__global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x3n_kernel(const X3nArgs a) {
   using G = NG<KK, CT, NT, TWO>;
   constexpr int MT = 4;                                        // wave w owns tile rows 4w .. 4w+3
   constexpr int PAD = (KK - 1) / 2;
