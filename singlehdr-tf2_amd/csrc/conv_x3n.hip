@@ -116,14 +116,17 @@ struct NG {
 // Waves per SIMD the register allocator is held to (rocm 7.2 spends registers freely when nothing bounds it: the 4 -> 64 image layer
 // <3,8,4> sat at 168 + 96 accumulation registers = one wave per SIMD for a kernel that fits 215, 0.386 -> 0.277 ms; the 3x3 tanh heads took
 // 9 registers more than their tanh-free twins and lost their third wave, 0.252 -> 0.203 ms): 3 for the 3x3 tanh heads, 2 wherever the
-// instantiation fits 256 registers without spilling (every 3x3 form, the 4(8)-channel image layers, 5x5 16 -> 16), unbounded for the
-// wide 5x5 / 7x7 forms, which would spill 30 - 400 registers (measured 2 - 4x slower)
+// instantiation fits 256 registers without spilling (all but the 5x5 32 -> 32 and the unused 7x7 32-channel forms, now that the tap
+// offsets are no longer hoisted out of the tile loop, see the k-step loop)
 template <int KK, int CT, int NT>
 constexpr int x3n_min_waves(bool tanh_head) {
 #ifdef SHDR_ABL_X3N_NO_BOUNDS
   return 1;
 #endif
-  return (tanh_head && KK == 3 && CT <= 16) ? 3 : (KK == 3 || CT == 8 || (KK == 5 && CT == 16 && NT == 1)) ? 2 : 1;
+#ifdef SHDR_ABL_X3N_ALL_TWO
+  return (tanh_head && KK == 3 && CT <= 16) ? 3 : 2;
+#endif
+  return (tanh_head && KK == 3 && CT <= 16) ? 3 : (KK == 5 && CT == 32 && NT == 2) ? 1 : (KK == 7 && CT == 32) ? 1 : 2;
 }
 template <int KK, int CT, int NT, bool TWO, bool TANH>
 __global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x3n_kernel(const X3nArgs a) {
@@ -304,6 +307,9 @@ __global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x
           toff = (jl == j) ? o : toff;
         }
       }
+      // opaque to the optimiser: the tap offsets are tile-invariant, and hoisted out of the persistent tile loop the MT x NS operand
+      // addresses of the unrolled k-steps were 100 - 250 live registers (7x7 16 -> 16: 256 + 116 registers = one wave per SIMD; 195 + 20 now)
+      asm volatile("" : "+v"(toff));
       f16x8 wh[NT], wl[NT], ws[NT], ph[MT], pl[MT];
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
