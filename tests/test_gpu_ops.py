@@ -793,7 +793,8 @@ def test_conv2d_x3n_input_gradient(shdr, case, monkeypatch):
     assert not torch.equal(dx, dxe)                     # ... and it did take another kernel
 
 
-@pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128)])
+@pytest.mark.parametrize("shape", [(2, 40, 56, 128, 128, 128), (1, 33, 47, 256, 0, 64), (1, 16, 16, 512, 512, 512), (3, 20, 20, 256, 0, 128),
+                                   (1, 24, 40, 96, 0, 64), (2, 18, 30, 96, 64, 128), (1, 20, 28, 64, 0, 256)])      # (3, 5 and 2 chunks: the two-deep prefetch)
 def test_conv2d_x3_1x1_layers(shdr, shape, monkeypatch):
     """1x1 layers (K >= 64) on the split-operand kernel (the hal skip layers on tf.concat with the 1/255 skip scale, the ResNet
     bottleneck convs): one tap per chunk; vs the float64 oracle at the exact-fp32 bar, ragged tiles"""
