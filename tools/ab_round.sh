@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU tests, then the four networks' forward on _base/ (the previous round's tree) and on this tree, then the bench line
+# GPU tests, then the four networks' forward on _base/ and on this tree, then the bench line.
+# _base/ = a checkout of the previous round's last commit with its library built and tools/net_one.py, tools/img_layers.py copied in
+# (git worktree add _base <commit> && python _base/singlehdr-tf2_amd/build.py); git-ignored, travels to the GPU box with the snapshot
 set -e
 python -m pytest tests -m gpu -q -x > gpurun_out/ab_tests.log 2>&1 || { tail -30 gpurun_out/ab_tests.log; exit 1; }
 tail -2 gpurun_out/ab_tests.log
