@@ -106,8 +106,17 @@ struct NG {
   static constexpr int PJ = (PIECES + 255) / 256;              // per thread
   static constexpr int PATCH_HALVES = PP * CT;                 // one fp16 image
   static constexpr int COUT = NT * 16;
-  static constexpr int FILT_HALVES = NS * COUT * 32;           // one image
-  static constexpr int FINSTR = 2 * NS * COUT / 16;            // filter DMA instructions, both images (16 rows of 64 bytes each)
+  // HALF: with 16 channels per tap and an odd tap count the last k-step carries ONE real tap; its rows are stored as 16 halves (the zero
+  // tap's half is neither stored nor read: its lanes are fed a zero patch operand) -- 512 bytes per image less, which is what puts two
+  // blocks of the 7x7 16 -> 16 kernel on a CU (82 192 -> 81 168 bytes; the limit is 81 920)
+#ifdef SHDR_ABL_X3N_NO_HALF
+  static constexpr bool HALF = false;
+#else
+  static constexpr bool HALF = !TWO && CT == 16 && (NTAPS % 2 == 1) && KK >= 5;      // (3x3: five k-steps, the special last one costs 8 %)
+#endif
+  static constexpr int FULL_STEPS = HALF ? NS - 1 : NS;
+  static constexpr int FILT_HALVES = FULL_STEPS * COUT * 32 + (HALF ? COUT * 16 : 0);      // one image
+  static constexpr int FINSTR = FULL_STEPS * COUT / 16;        // filter DMA instructions per image for the full steps (16 rows of 64 bytes each)
   static constexpr int IMAGE_BYTES = (2 * FILT_HALVES + 2 * PATCH_HALVES) * 2;
   static constexpr int LDS_BYTES = IMAGE_BYTES + 16;           // + the waves' output maxima (xn_range_out)
 };
@@ -143,11 +152,21 @@ __global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- both filter images -> LDS, once per block (rows of 64 bytes, physical slot = k-group ^ swz(cout)) ---------------------------
-  for (int j = wave; j < G::FINSTR; j += 4) {
-    const int r = j * 16 + (lane >> 2);                        // row = (image * NS + step) * COUT + cout
+  for (int j = wave; j < 2 * G::FINSTR; j += 4) {
+    const int img = j >= G::FINSTR, jj = j - img * G::FINSTR;
+    const int r = jj * 16 + (lane >> 2);                       // row = step * COUT + cout of image img
     const int co = r % G::COUT;
-    const _Float16* p = a.wp + (size_t)r * 32 + 8 * ((lane & 3) ^ pswz(co));
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(nsm + j * 512), 16, 0, 0);
+    const _Float16* p = a.wp + img * G::FILT_HALVES + (size_t)r * 32 + 8 * ((lane & 3) ^ pswz(co));
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(nsm + img * G::FILT_HALVES + jj * 512), 16, 0, 0);
+  }
+  if (G::HALF && wave < 2) {                                   // the 32-byte rows of the last k-step: two lanes per row, one (partial) instruction per image
+    static_assert(!G::HALF || G::COUT <= 32, "one DMA instruction covers 32 half rows");
+    const int co = lane >> 1;
+    if (co < G::COUT) {
+      const int base = wave * G::FILT_HALVES + G::FULL_STEPS * G::COUT * 32;
+      const _Float16* p = a.wp + base + co * 16 + 8 * ((lane & 1) ^ (pswz(co) & 1));
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(nsm + base), 16, 0, 0);
+    }
   }
 
   // ---- patch geometry: piece = tid + 256 j -> (source, patch pixel, float4 of the pixel), fixed over the tiles ---------------------
@@ -311,10 +330,16 @@ __global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x
       // addresses of the unrolled k-steps were 100 - 250 live registers (7x7 16 -> 16: 256 + 116 registers = one wave per SIMD; 195 + 20 now)
       asm volatile("" : "+v"(toff));
       f16x8 wh[NT], wl[NT], ws[NT], ph[MT], pl[MT];
+      const bool last_half = G::HALF && s == G::NS - 1;       // (compile-time: the loop is unrolled)
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
-        wh[ni] = *reinterpret_cast<const f16x8*>(filt_h + s * G::COUT * 32 + b_rd[ni]);
-        wl[ni] = *reinterpret_cast<const f16x8*>(filt_l + s * G::COUT * 32 + b_rd[ni]);
+        int bo = s * G::COUT * 32 + b_rd[ni];
+        if (last_half) {                                         // 16-half rows; the lanes of the absent tap alias the real one's (finite) weights
+          const int row = ni * 16 + fi;
+          bo = s * G::COUT * 32 + row * 16 + 8 * ((fg & 1) ^ (pswz(row) & 1));
+        }
+        wh[ni] = *reinterpret_cast<const f16x8*>(filt_h + bo);
+        wl[ni] = *reinterpret_cast<const f16x8*>(filt_l + bo);
         ws[ni] = wh[ni] * (_Float16)(1.0f / 2048.0f);
       }
 #pragma unroll
@@ -326,6 +351,10 @@ __global__ __launch_bounds__(256, (x3n_min_waves<KK, CT, NT>(TANH))) void conv_x
         }
         ph[mi] = *reinterpret_cast<const f16x8*>(patch_h + ad);
         pl[mi] = *reinterpret_cast<const f16x8*>(patch_l + ad);
+        if (last_half && jl > 0) {                               // the absent tap of the last k-step: a zero operand
+          ph[mi] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          pl[mi] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
       }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
@@ -455,7 +484,8 @@ __global__ __launch_bounds__(256) void x3n_absmax_kernel(const float* __restrict
 // packed[image][step][co][k]: k = (tap, channel) in natural order, CT channels per tap (the source's C1 [+ C2] real ones, zero beyond),
 // zero beyond the last tap and beyond the real couts; w * x2-scale * 2^S split into wh, wl
 __global__ __launch_bounds__(256) void x3n_pack_kernel(const float* __restrict__ w, float* __restrict__ hdr, _Float16* __restrict__ out, int ntaps,
-                                                       int CT, int C1, int Creal, int cout_real, int Cout_w, int COUT, int NS, float x2_scale) {
+                                                       int CT, int C1, int Creal, int cout_real, int Cout_w, int COUT, int NS, float x2_scale,
+                                                       int half_last) {
   const float mx = fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[0]) * fmaxf(1.0f, fabsf(x2_scale)), 1e-30f);
   int ex;
   frexpf(mx, &ex);
@@ -463,9 +493,17 @@ __global__ __launch_bounds__(256) void x3n_pack_kernel(const float* __restrict__
   S = S < -100 ? -100 : (S > 100 ? 100 : S);
   const float s = ldexpf(1.0f, S);
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = ldexpf(1.0f, -S);
-  const long total = (long)NS * COUT * 32;
+  // half_last (NG::HALF): the last k-step holds one 16-channel tap: rows of 16 halves instead of 32
+  const long full = (long)(NS - (half_last ? 1 : 0)) * COUT * 32;
+  const long total = full + (half_last ? COUT * 16 : 0);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int kk = (int)(e & 31), co = (int)((e >> 5) % COUT), st = (int)(e / (32L * COUT));
+    int kk, co, st;
+    if (e < full) {
+      kk = (int)(e & 31); co = (int)((e >> 5) % COUT); st = (int)(e / (32L * COUT));
+    } else {
+      const int e2 = (int)(e - full);
+      kk = e2 & 15; co = e2 >> 4; st = NS - 1;
+    }
     const int k = st * 32 + kk;
     const int tap = k / CT, ch = k - tap * CT;
     float v = 0.0f;
@@ -576,7 +614,11 @@ extern "C" int shdr_conv2d_x3n_prepare_filter_premax_f32(const shdr_conv2d_desc*
   }
   hipLaunchKernelGGL(x3n_pack_kernel, dim3(shdr::stream_grid((long)ns * d->Cout * 32)), dim3(256), 0, st, w, prepared,
                      reinterpret_cast<_Float16*>(prepared + XN_HEADER_FLOATS), ntaps, ct, d->C1, Creal, cv, d->Cout, d->Cout, ns,
-                     d->C2 > 0 ? d->x2_scale : 1.0f);
+#ifdef SHDR_ABL_X3N_NO_HALF
+                     d->C2 > 0 ? d->x2_scale : 1.0f, 0);
+#else
+                     d->C2 > 0 ? d->x2_scale : 1.0f, (d->C2 == 0 && ct == 16 && ntaps % 2 == 1 && ntaps >= 25) ? 1 : 0);       // NG::HALF
+#endif
   return shdr::check_launch("conv2d_x3n_prepare_filter");
 }
 
