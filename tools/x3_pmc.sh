@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"
 HW="${1:-64}"; CIN="${2:-512}"; COUT="${3:-512}"
 TAG="${4:-${HW}_${CIN}_${COUT}}"
+KS="${5:-3}"; C2="${6:-0}"                                   # kernel size (3 or 1) and channels of a second source
 O="$R/gpurun_out/x3_pmc/$TAG"
 mkdir -p "$O"
 i=0
@@ -15,7 +16,7 @@ IFS=';' read -ra SETS <<< "${X3_PMC_SETS:-$DEFAULT_SETS}"       # X3_PMC_SETS="A
 for SET in "${SETS[@]}"; do
   i=$((i+1))
   # shellcheck disable=SC2086
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$O/p$i" -- python3 "$R/tools/x3_one.py" "$HW" "$CIN" "$COUT" > "$O/p$i.log" 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$O/p$i" -- python3 "$R/tools/x3_one.py" "$HW" "$CIN" "$COUT" 16 "$KS" "$C2" > "$O/p$i.log" 2>&1 || echo "pass $i failed"
 done
 cd "$R" && python3 - "$O" "$TAG" <<'PY'
 import csv, glob, collections, sys
